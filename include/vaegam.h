@@ -1,0 +1,129 @@
+/* vaegam.h -- C ABI of libvaegam_hip.so: the MI355X (gfx950) kernels under the VAE-GAM train step.
+ *
+ * The reference (dannyfa/VAE-GAM) is pure Python on PyTorch and has no FFI: every entry point
+ * below replaces a group of ATen calls made from `VAE.forward` / `loss.backward()` /
+ * `optimizer.step()`; the reference lines are cited per function.  Conventions:
+ *   - every pointer is a DEVICE pointer into memory owned by the caller (PyTorch tensors);
+ *     the library allocates nothing persistent and frees nothing;
+ *   - every launch is asynchronous on the `stream` handed in (a hipStream_t passed as void*);
+ *   - return value: 0 = OK, non-zero = vg_status; text via vg_last_error(); no exceptions;
+ *   - activations are fp32, NCDHW, contiguous.  Layers store PRE-activation values; the
+ *     consumer applies ReLU and the batch-norm affine when it loads them (`vg_prologue`).
+ *   - "group": the decoder runs C+1 one-hot variants in one launch (sample n -> group
+ *     n / per_group); batch-norm statistics are kept per group (vae_reg_GP.py:330,343 call
+ *     decode() separately per variant, each with its own batch statistics).
+ */
+#ifndef VAEGAM_H
+#define VAEGAM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vg_conv_desc {
+    int32_t N;                 /* samples in this launch */
+    int32_t CI, CO;            /* channels of the tensor read / written by THIS launch */
+    int32_t ID, IH, IW;        /* spatial size of the tensor read */
+    int32_t OD, OH, OW;        /* spatial size of the tensor written */
+    int32_t KD, KH, KW;        /* kernel */
+    int32_t stride;            /* 1 or 2 */
+    int32_t pad_d, pad_h, pad_w; /* corr: leading zero padding of the input; tconv: ConvTranspose3d padding */
+    int32_t relu_in;           /* prologue: max(x,0) on load */
+    int32_t per_group;         /* samples per affine group for in_scale/in_shift ([N/per_group][CI]) */
+} vg_conv_desc;
+
+/* library identity / errors */
+int         vg_version(void);
+const char* vg_last_error(void);
+
+/* y[n][co][o] = bias[co] + sum_{ci,k} P(x)[n][ci][o*stride + k - pad] * wpk[ci][k][co]
+ * (zero outside the input).  P = prologue (ReLU, then x*in_scale[g][ci]+in_shift[g][ci]).
+ * Replaces F.conv3d forward (vae_reg_GP.py:238-242), ConvTranspose3d stride-1 forward with a
+ * flipped repacked kernel (:260,262,264) and the data gradients of ConvTranspose3d (autograd
+ * of :260-264).  If mask_src != NULL the result is multiplied by (mask_src[same index] > 0):
+ * the ReLU backward of the producer layer fused into the data-gradient epilogue. */
+int vg_corr3d(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias,
+              const float* in_scale, const float* in_shift, const float* mask_src, float* y, void* stream);
+
+/* stride-2 transposed convolution, gather form:
+ * y[n][co][o] = bias[co] + sum_{ci,k : (o+pad-k) even} P(x)[n][ci][(o+pad-k)/2] * wpk[ci][k][co].
+ * Replaces ConvTranspose3d stride-2 forward (vae_reg_GP.py:261,263) and the data gradient of
+ * the stride-2 Conv3d layers (autograd of :239,241). mask_src as above. */
+int vg_tconv3d_s2(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias,
+                  const float* in_scale, const float* in_shift, const float* mask_src, float* y, void* stream);
+
+/* weight gradient:  dw[cb][ca][k] = sum_{n,p} PB(b)[n][cb][p] * PA(a)[n][ca][p*stride + k - pad]
+ * b: [N][CB][PD][PH][PW], a: [N][CA][AD][AH][AW] (zero outside).  For a Conv3d layer b = dy,
+ * a = layer input (prologue on a); for a ConvTranspose3d layer b = layer input (prologue on b),
+ * a = dy.  dw comes out in the layer's own weight layout.  Replaces autograd's conv weight
+ * gradients.  `ws` is caller workspace of vg_wgrad3d_ws_bytes() bytes. */
+typedef struct vg_wgrad_desc {
+    int32_t N, CB, CA;
+    int32_t PD, PH, PW;        /* spatial size of b */
+    int32_t AD, AH, AW;        /* spatial size of a */
+    int32_t KD, KH, KW;
+    int32_t stride;
+    int32_t pad_d, pad_h, pad_w;
+    int32_t pro_on_a;          /* 1: prologue applies to a, 0: to b */
+    int32_t relu_in;
+    int32_t per_group;
+} vg_wgrad_desc;
+int64_t vg_wgrad3d_ws_bytes(const vg_wgrad_desc* d);
+int vg_wgrad3d(const vg_wgrad_desc* d, const float* a, const float* b, const float* in_scale,
+               const float* in_shift, float* ws, float* dw, void* stream);
+
+/* batch-norm batch statistics (BatchNorm3d(track_running_stats=False), vae_reg_GP.py:194-196,
+ * 216-218): for x [N][C][P], group g = n / per_group: mean/var over (per_group samples, P) of
+ * relu?(x); writes scale = gamma*rstd, shift = beta - mean*scale, mean, rstd ([G][C] each).
+ * ws: caller workspace of vg_bn_ws_bytes(N, C, P, per_group) bytes.
+ * If ext_sums != NULL the kernel stops after writing the raw per-(g,c) [sum, sumsq, count]
+ * triples there (double[G][C][3]) so the caller can all-reduce them across ranks, and
+ * vg_bn_finalize() turns reduced triples into scale/shift/mean/rstd. */
+int64_t vg_bn_ws_bytes(int32_t N, int32_t C, int64_t P, int32_t per_group);
+int vg_bn_stats(const float* x, int32_t N, int32_t C, int64_t P, int32_t per_group, int32_t relu,
+                const float* gamma, const float* beta, float eps, void* ws, double* ext_sums,
+                float* scale, float* shift, float* mean, float* rstd, void* stream);
+int vg_bn_finalize(const double* sums, int32_t G, int32_t C, const float* gamma, const float* beta,
+                   float eps, float* scale, float* shift, float* mean, float* rstd, void* stream);
+
+/* batch-norm backward through h = relu?(p), xe = (h-mean)*rstd*gamma+beta, given dxe (in place):
+ *   dgamma_part[g][c] = sum dxe*hhat, dbeta_part[g][c] = sum dxe,
+ *   dp = relu'(p) * gamma*rstd * (dxe - mean(dxe) - hhat*mean(dxe*hhat)).
+ * Two entry points so a data-parallel caller can all-reduce the (double[G][C][2]) sums between. */
+int vg_bn_bwd_reduce(const float* dxe, const float* p, int32_t N, int32_t C, int64_t P, int32_t per_group,
+                     int32_t relu, const float* mean, const float* rstd, void* ws, double* sums, void* stream);
+int vg_bn_bwd_apply(float* dxe_inout, const float* p, int32_t N, int32_t C, int64_t P, int32_t per_group,
+                    int32_t relu, const float* gamma, const float* mean, const float* rstd,
+                    const double* sums, double count, float* dgamma_part, float* dbeta_part, void* stream);
+
+/* per-channel sum of a [N][C][P] tensor (bias gradients): out[c] = sum_{n,p} x[n][c][p] */
+int vg_channel_sum(const float* x, int32_t N, int32_t C, int64_t P, void* ws, float* out, void* stream);
+
+/* fused GAM accumulate + ELBO + GLM distance (vae_reg_GP.py:380,388-390,400-406).
+ *   logits [G=C+1][B][V]: decoder pre-sigmoid outputs (group 0 = base map, group i = effect map i)
+ *   gain   [C][B]: task_var per covariate;  x [B][V];  eps [V] float64 (log-precision map);
+ *   glm [C][V] fp32 (GLM map of covariate i);
+ * outputs: sum_log_prob[B] = sum_v log N(x | x_rec, exp(-eps)),  dist[C][B] = ||cons_ib - glm_i||_2,
+ *   optional maps_out [G+1][B][V] = sigmoid(base), cons_1..C, full reconstruction (reconstruct path). */
+int64_t vg_gam_ws_bytes(int32_t C, int32_t B, int64_t V);
+int vg_gam_elbo_fwd(const float* logits, const float* gain, const float* x, const double* eps,
+                    const float* glm, int32_t C, int32_t B, int64_t V, void* ws,
+                    float* sum_log_prob, float* dist, float* maps_out, void* stream);
+/* backward: given g_slp[B] = dL/dsum_log_prob and g_dist[C][B] = dL/ddist, writes
+ *   d_logits[G][B][V] (sigmoid backward fused), d_gain[C][B], d_eps[V] (float64). */
+int vg_gam_elbo_bwd(const float* logits, const float* gain, const float* x, const double* eps,
+                    const float* glm, const float* dist, const float* g_slp, const float* g_dist,
+                    int32_t C, int32_t B, int64_t V, void* ws,
+                    float* d_logits, float* d_gain, double* d_eps, void* stream);
+
+/* fused Adam (torch.optim.Adam defaults, vae_reg_GP.py:179,429) over one flat buffer:
+ * p,g,m,v: n elements of fp32 (is_f64 = 0) or fp64 (is_f64 = 1).  step_size = lr/(1-b1^t),
+ * bc2_sqrt = sqrt(1-b2^t) are passed as device scalars [2] so a captured graph can replay
+ * with a changing step count. */
+int vg_adam_step(void* p, const void* g, void* m, void* v, int64_t n, int32_t is_f64,
+                 double b1, double b2, double eps, const double* step_scalars, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAEGAM_H */

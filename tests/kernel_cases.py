@@ -1,0 +1,133 @@
+"""Shared bodies of the kernel parity tests: each HIP operator against a plain PyTorch fp32
+reference of the same maths.  Run on CPU tensors through the host build of the kernels
+(tests/emu, index-arithmetic check) and on the GPU through libvaegam_hip.so (-m gpu)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import vae_gam_amd  # noqa: F401
+from vae_gam_amd import ops
+from vae_gam_amd.ops import ConvSpec
+
+# (name, spec, small input size) -- one entry per layer of vae_reg_GP.py:189-215, spatial sizes shrunk
+LAYERS = [
+    ('conv1', ConvSpec('conv', 1, 8, (3, 3, 3), 1), (7, 9, 8)),
+    ('conv2', ConvSpec('conv', 8, 8, (3, 3, 3), 2), (9, 11, 8)),
+    ('conv3', ConvSpec('conv', 8, 16, (3, 3, 3), 1), (5, 7, 6)),
+    ('conv4', ConvSpec('conv', 16, 16, (3, 3, 3), 2), (7, 9, 6)),
+    ('conv5', ConvSpec('conv', 16, 16, (3, 3, 3), 1), (4, 5, 3)),
+    ('convt1', ConvSpec('convt', 16, 16, (3, 3, 3), 1), (3, 4, 5)),
+    ('convt2', ConvSpec('convt', 16, 16, (3, 3, 3), 2, (1, 0, 1), (1, 0, 1)), (4, 5, 4)),
+    ('convt3', ConvSpec('convt', 16, 8, (3, 3, 3), 1), (4, 6, 5)),
+    ('convt4', ConvSpec('convt', 8, 8, (5, 3, 3), 2), (4, 5, 4)),
+    ('convt5', ConvSpec('convt', 8, 1, (3, 3, 3), 1), (5, 7, 6)),
+]
+
+
+def ref_layer(p, w, b, gamma, beta, spec, relu_in, per_group):
+    h = F.relu(p) if relu_in else p
+    if gamma is not None:
+        N, C = h.shape[:2]
+        G = N // per_group
+        hg = h.reshape(G, per_group, C, -1)
+        mean = hg.mean((1, 3), keepdim=True)
+        var = hg.var((1, 3), unbiased=False, keepdim=True)
+        hg = (hg - mean) / torch.sqrt(var + 1e-5) * gamma.view(1, 1, -1, 1) + beta.view(1, 1, -1, 1)
+        h = hg.reshape(h.shape)
+    if spec.kind == 'conv':
+        return F.conv3d(h, w, b, spec.stride)
+    return F.conv_transpose3d(h, w, b, spec.stride, spec.pad, spec.outpad)
+
+
+def run_layer_case(dev, name, spec, isz, with_bn, relu_in, groups, input_is_data=False, seed=0, tol=2e-4):
+    g = torch.Generator().manual_seed(seed)
+    per_group = 2
+    N = per_group * groups
+    wshape = ((spec.co, spec.ci) if spec.kind == 'conv' else (spec.ci, spec.co)) + tuple(spec.k)
+    p = torch.randn((N, spec.ci) + tuple(isz), generator=g)
+    w = torch.randn(wshape, generator=g) * 0.2
+    b = torch.randn(spec.co, generator=g) * 0.1
+    gamma = (1 + 0.3 * torch.randn(spec.ci, generator=g)) if with_bn else None
+    beta = (0.2 * torch.randn(spec.ci, generator=g)) if with_bn else None
+    leaves = [t.clone().requires_grad_(True) if t is not None else None for t in (p, w, b, gamma, beta)]
+    y_ref = ref_layer(*leaves, spec, relu_in, per_group)
+    gy = torch.randn(y_ref.shape, generator=g)
+    ref_grads = torch.autograd.grad(y_ref, [t for t in leaves if t is not None], gy)
+    ref_grads = list(ref_grads)
+    if gamma is None:
+        ref_grads += [None, None]
+
+    dleaves = [t.to(dev).clone().requires_grad_(True) if t is not None else None for t in (p, w, b, gamma, beta)]
+    if input_is_data:
+        dleaves[0] = dleaves[0].detach()
+    y = ops.bn_conv_act(dleaves[0], dleaves[1], dleaves[2], dleaves[3], dleaves[4], spec, relu_in, per_group, input_is_data)
+    assert y.shape == y_ref.shape, (y.shape, y_ref.shape)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), y_ref.detach().numpy(), rtol=tol, atol=tol, err_msg=name + ' fwd')
+    ins = [t for t in dleaves if t is not None and t.requires_grad]
+    grads = list(torch.autograd.grad(y, ins, gy.to(dev)))
+    names = ['p', 'w', 'b', 'gamma', 'beta']
+    k = 0
+    for i, t in enumerate(dleaves):
+        if t is None or not t.requires_grad:
+            continue
+        got = grads[k].cpu().numpy(); k += 1
+        want = ref_grads[i].numpy()
+        scale = max(1.0, float(np.abs(want).max()))
+        np.testing.assert_allclose(got, want, rtol=5 * tol, atol=5 * tol * scale, err_msg='%s d%s' % (name, names[i]))
+
+
+def ref_gam(logits, gain, x, eps, glm):
+    G, B, V = logits.shape
+    s = torch.sigmoid(logits)
+    xrec = s[0]
+    dist = []
+    for i in range(1, G):
+        cons = gain[i - 1][:, None] * s[i]
+        dist.append(torch.linalg.vector_norm(cons - glm[i - 1][None], dim=1))
+        xrec = xrec + cons
+    scale = torch.exp(-eps).float()[None]
+    lp = -((x - xrec) ** 2) / (2 * scale ** 2) - scale.log() - np.log(np.sqrt(2 * np.pi))
+    return lp.sum(1), (torch.stack(dist) if dist else torch.zeros(0, B))
+
+
+def run_gam_case(dev, C, B, V, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(C + 1, B, V, generator=g)
+    gain = torch.randn(C, B, generator=g)
+    x = torch.rand(B, V, generator=g)
+    eps = (-np.log(10) + 0.3 * torch.randn(V, generator=g, dtype=torch.float64))
+    glm = torch.rand(C, V, generator=g)
+    lv = [logits.clone().requires_grad_(True), gain.clone().requires_grad_(True), x, eps.clone().requires_grad_(True), glm]
+    slp_r, dist_r = ref_gam(*lv)
+    g1 = torch.randn(B, generator=g); g2 = torch.randn(C, B, generator=g)
+    tgt = [lv[0], lv[3]] + ([lv[1]] if C > 0 else [])
+    gr = torch.autograd.grad((slp_r * g1).sum() + (dist_r * g2).sum(), tgt)
+    dv = [logits.to(dev).clone().requires_grad_(True), gain.to(dev).clone().requires_grad_(True), x.to(dev), eps.to(dev).clone().requires_grad_(True), glm.to(dev)]
+    slp, dist = ops.GamElbo.apply(*dv)
+    np.testing.assert_allclose(slp.detach().cpu().numpy(), slp_r.detach().numpy(), rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(dist.detach().cpu().numpy(), dist_r.detach().numpy(), rtol=2e-5, atol=1e-5)
+    dtgt = [dv[0], dv[3]] + ([dv[1]] if C > 0 else [])
+    gd = torch.autograd.grad((slp * g1.to(dev)).sum() + (dist * g2.to(dev)).sum(), dtgt)
+    for a, b_, nm in zip(gd, gr, ('d_logits', 'd_eps', 'd_gain')):
+        sc = max(1.0, float(b_.abs().max()))
+        np.testing.assert_allclose(a.cpu().numpy(), b_.numpy(), rtol=2e-4, atol=2e-5 * sc, err_msg=nm)
+    maps = ops.gam_maps(dv[0].detach(), dv[1].detach(), dv[2], dv[3].detach(), dv[4])
+    s = torch.sigmoid(logits)
+    np.testing.assert_allclose(maps[0].cpu().numpy(), s[0].numpy(), atol=1e-6)
+    full = s[0] + sum(gain[i][:, None] * s[i + 1] for i in range(C))
+    np.testing.assert_allclose(maps[C + 1].cpu().numpy(), full.numpy(), atol=1e-5)
+
+
+def run_adam_case(dev, dtype, n=5000, steps=3, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    p0 = torch.randn(n, generator=g, dtype=dtype)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    p = p0.to(dev).clone(); m = torch.zeros_like(p); v = torch.zeros_like(p)
+    for t in range(1, steps + 1):
+        gr = torch.randn(n, generator=g, dtype=dtype)
+        ref.grad = gr.clone(); opt.step()
+        sc = torch.tensor([1e-3 / (1 - 0.9 ** t), np.sqrt(1 - 0.999 ** t)], dtype=torch.float64, device=dev)
+        ops.adam_step_(p, gr.to(dev), m, v, 0.9, 0.999, 1e-8, sc)
+    tol = 1e-6 if dtype == torch.float32 else 1e-12
+    np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=tol, atol=tol)

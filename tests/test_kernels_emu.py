@@ -1,0 +1,56 @@
+"""Host build of the HIP kernel sources (tests/emu, g++ -DVG_EMU) against PyTorch references on
+tiny shapes: checks tile/halo/index arithmetic and barrier structure without a GPU.  The -m gpu
+twin (tests/test_kernels_gpu.py) runs the same bodies on libvaegam_hip.so."""
+import os
+import subprocess
+
+import pytest
+import torch
+
+import vae_gam_amd  # noqa: F401
+from vae_gam_amd import _lib
+import kernel_cases as K
+
+EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu')
+
+
+@pytest.fixture(scope='module', autouse=True)
+def emu_lib():
+    so = os.path.join(EMU_DIR, 'libvaegam_emu.so')
+    srcs = [os.path.join(EMU_DIR, f) for f in os.listdir(EMU_DIR) if f.endswith(('.h', '.cpp', '.sh'))]
+    csrc = os.path.join(os.path.dirname(EMU_DIR), '..', 'vae-gam_amd', 'csrc')
+    srcs += [os.path.join(csrc, f) for f in os.listdir(csrc)]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call([os.path.join(EMU_DIR, 'build_emu.sh')])
+    prev = _lib._LIB
+    _lib.set_library_for_tests(_lib.VgLibrary(so))
+    yield
+    _lib.set_library_for_tests(prev)
+
+
+@pytest.mark.parametrize('name,spec,isz', K.LAYERS, ids=[l[0] for l in K.LAYERS])
+def test_layer_bn_relu(name, spec, isz):
+    K.run_layer_case('cpu', name, spec, isz, with_bn=True, relu_in=(name != 'conv1'), groups=2 if spec.kind == 'convt' else 1)
+
+
+@pytest.mark.parametrize('name,spec,isz', [K.LAYERS[1], K.LAYERS[3], K.LAYERS[6], K.LAYERS[8]], ids=['conv2', 'conv4', 'convt2', 'convt4'])
+def test_layer_relu_only(name, spec, isz):
+    K.run_layer_case('cpu', name, spec, isz, with_bn=False, relu_in=True, groups=1, seed=3)
+
+
+def test_first_layer_input_is_data():
+    name, spec, isz = K.LAYERS[0]
+    K.run_layer_case('cpu', name, spec, isz, with_bn=True, relu_in=False, groups=1, input_is_data=True, seed=5)
+
+
+def test_gam_elbo():
+    K.run_gam_case('cpu', C=3, B=3, V=1500)
+
+
+def test_gam_elbo_no_covariates():
+    K.run_gam_case('cpu', C=0, B=2, V=700, seed=2)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_adam(dtype):
+    K.run_adam_case('cpu', dtype)

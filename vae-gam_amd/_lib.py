@@ -1,0 +1,92 @@
+"""ctypes binding of the C ABI in include/vaegam.h (libvaegam_hip.so).
+
+The product path loads ONLY the hipcc-built library that sits next to this file and fails
+loudly if it is missing -- there is no CPU fallback.  (`tests/emu` builds the same sources
+for the host to debug index arithmetic; tests inject that handle explicitly through
+`set_library_for_tests`, the product never looks for it.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = 'libvaegam_hip.so'
+
+i32, i64, f32, f64, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, i32) for n in ('N', 'CI', 'CO', 'ID', 'IH', 'IW', 'OD', 'OH', 'OW', 'KD', 'KH', 'KW',
+                                   'stride', 'pad_d', 'pad_h', 'pad_w', 'relu_in', 'per_group')]
+
+
+class WgradDesc(ctypes.Structure):
+    _fields_ = [(n, i32) for n in ('N', 'CB', 'CA', 'PD', 'PH', 'PW', 'AD', 'AH', 'AW', 'KD', 'KH', 'KW',
+                                   'stride', 'pad_d', 'pad_h', 'pad_w', 'pro_on_a', 'relu_in', 'per_group')]
+
+
+_PROTOS = {
+    'vg_version': (ctypes.c_int, []),
+    'vg_last_error': (ctypes.c_char_p, []),
+    'vg_corr3d': (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
+    'vg_tconv3d_s2': (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
+    'vg_wgrad3d_ws_bytes': (i64, [ctypes.POINTER(WgradDesc)]),
+    'vg_wgrad3d': (ctypes.c_int, [ctypes.POINTER(WgradDesc), vp, vp, vp, vp, vp, vp, vp]),
+    'vg_bn_ws_bytes': (i64, [i32, i32, i64, i32]),
+    'vg_bn_stats': (ctypes.c_int, [vp, i32, i32, i64, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),
+    'vg_bn_finalize': (ctypes.c_int, [vp, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp]),
+    'vg_bn_bwd_reduce': (ctypes.c_int, [vp, vp, i32, i32, i64, i32, i32, vp, vp, vp, vp, vp]),
+    'vg_bn_bwd_apply': (ctypes.c_int, [vp, vp, i32, i32, i64, i32, i32, vp, vp, vp, vp, f64, vp, vp, vp]),
+    'vg_channel_sum': (ctypes.c_int, [vp, i32, i32, i64, vp, vp, vp]),
+    'vg_gam_ws_bytes': (i64, [i32, i32, i64]),
+    'vg_gam_elbo_fwd': (ctypes.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, vp]),
+    'vg_gam_elbo_bwd': (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, vp]),
+    'vg_adam_step': (ctypes.c_int, [vp, vp, vp, vp, i64, i32, f64, f64, f64, vp, vp]),
+}
+EXPORTS = tuple(_PROTOS)
+
+
+class VgError(RuntimeError):
+    pass
+
+
+class VgLibrary:
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise VgError('HIP kernel library %s not found: run `python -c "import __graft_entry__ as g; g.build()"` '
+                          '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % path)
+        self.path = path
+        self.dll = ctypes.CDLL(path)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(self.dll, name)           # AttributeError here = a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+
+    def call(self, name, *args):
+        rc = getattr(self.dll, name)(*args)
+        if rc != 0:
+            raise VgError('%s failed (status %d): %s' % (name, rc, self.dll.vg_last_error().decode()))
+
+    def size(self, name, *args):
+        n = getattr(self.dll, name)(*args)
+        if n < 0:
+            raise VgError('%s: unsupported configuration: %s' % (name, self.dll.vg_last_error().decode()))
+        return int(n)
+
+
+_LIB = None
+
+
+def library_path():
+    return os.path.join(_HERE, LIB_NAME)
+
+
+def get_lib() -> VgLibrary:
+    global _LIB
+    if _LIB is None:
+        _LIB = VgLibrary(library_path())
+    return _LIB
+
+
+def set_library_for_tests(lib):
+    """tests only: inject a handle (e.g. the host build of the kernels under tests/emu)."""
+    global _LIB
+    _LIB = lib

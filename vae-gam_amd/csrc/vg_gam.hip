@@ -1,0 +1,259 @@
+// vg_gam.hip -- fused GAM accumulate + Gaussian log-likelihood + GLM distance, and fused Adam (gfx950).
+//
+// Replaces, per minibatch (vae_reg_GP.py):
+//   cons_i = task_var_i[:,None] * sigmoid(logits_i)   (:380, with the decoder's sigmoid :264 folded in)
+//   x_rec  = sigmoid(logits_0) + sum_i cons_i         (:330, :390)
+//   dist   = || cons_i[b] - glm_i ||_2                (:388; sum(cdist(..)) == B * sum_b dist)
+//   slp[b] = sum_v log N(x[b,v] | x_rec[b,v], exp(-eps[v]))   (:401-405)
+// in ONE pass over the (C+1) x B x V logits instead of 3-4 elementwise passes per covariate plus
+// the (C+2) x B x V device-to-host copies, and the matching backward in one more pass.
+// HBM-streaming kernels: coalesced loads, per-wave shuffle reductions, fixed-order second stage.
+#include "vg_common.h"
+#include "../../include/vaegam.h"
+
+namespace {
+
+constexpr int GT = 256;          // threads per block
+constexpr int GV = 4;            // voxels per thread (strided by GT -> coalesced dword loads)
+constexpr int GMAXC = 16;        // covariates supported by the LDS reduction scratch
+constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
+
+// grid (vchunks, B).  part_slp[b][chunk], part_d2[i][b][chunk]
+__global__ void __launch_bounds__(GT)
+gam_fwd_k(const float* __restrict__ logits, const float* __restrict__ gain, const float* __restrict__ x,
+          const double* __restrict__ eps, const float* __restrict__ glm, int C, int B, long long V,
+          float* __restrict__ part_slp, float* __restrict__ part_d2, float* __restrict__ maps_out) {
+    __shared__ float red[GT / VG_WAVE][GMAXC + 1];
+    const int chunk = blockIdx.x, b = blockIdx.y, chunks = gridDim.x;
+    const int lane = threadIdx.x % VG_WAVE, wave = threadIdx.x / VG_WAVE;
+    const long long v0 = (long long)chunk * GT * GV + threadIdx.x;
+    float xrec[GV];
+    bool ok[GV];
+#pragma unroll
+    for (int k = 0; k < GV; ++k) { ok[k] = (v0 + (long long)k * GT) < V; xrec[k] = 0.f; }
+    const size_t BV = (size_t)B * V;
+    // base map
+#pragma unroll
+    for (int k = 0; k < GV; ++k)
+        if (ok[k]) {
+            const long long v = v0 + (long long)k * GT;
+            const float s = sigmoidf_(logits[(size_t)b * V + v]);
+            xrec[k] = s;
+            if (maps_out) maps_out[(size_t)b * V + v] = s;
+        }
+    for (int i = 1; i <= C; ++i) {
+        const float gn = gain[(size_t)(i - 1) * B + b];
+        float d2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < GV; ++k)
+            if (ok[k]) {
+                const long long v = v0 + (long long)k * GT;
+                const float cons = gn * sigmoidf_(logits[(size_t)i * BV + (size_t)b * V + v]);
+                const float df = cons - glm[(size_t)(i - 1) * V + v];
+                d2 = fmaf(df, df, d2);
+                xrec[k] += cons;
+                if (maps_out) maps_out[(size_t)i * BV + (size_t)b * V + v] = cons;
+            }
+        d2 = wsum(d2);
+        if (lane == 0) red[wave][i] = d2;
+    }
+    float lp = 0.f;
+#pragma unroll
+    for (int k = 0; k < GV; ++k)
+        if (ok[k]) {
+            const long long v = v0 + (long long)k * GT;
+            const float sg = (float)exp(-eps[v]);               // fp64 exp then cast, as :402
+            const float r = x[(size_t)b * V + v] - xrec[k];
+            lp += -(r * r) / (2.f * sg * sg) - logf(sg) - LOG_SQRT_2PI;   // Normal.log_prob
+            if (maps_out) maps_out[(size_t)(C + 1) * BV + (size_t)b * V + v] = xrec[k];
+        }
+    lp = wsum(lp);
+    if (lane == 0) red[wave][0] = lp;
+    __syncthreads();
+    if (threadIdx.x <= C) {
+        float t = 0.f;
+        for (int w = 0; w < GT / VG_WAVE; ++w) t += red[w][threadIdx.x];
+        if (threadIdx.x == 0) part_slp[(size_t)b * chunks + chunk] = t;
+        else part_d2[((size_t)(threadIdx.x - 1) * B + b) * chunks + chunk] = t;
+    }
+}
+
+// one thread per output: slp[b] = sum chunks; dist[i][b] = sqrt(sum chunks)
+__global__ void gam_fwd_fold_k(const float* __restrict__ part_slp, const float* __restrict__ part_d2, int C, int B,
+                               int chunks, float* __restrict__ slp, float* __restrict__ dist) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (C + 1) * B) return;
+    const float* src = (i < B) ? part_slp + (size_t)i * chunks : part_d2 + (size_t)(i - B) * chunks;
+    double a = 0;
+    for (int k = 0; k < chunks; ++k) a += src[k];
+    if (i < B) slp[i] = (float)a; else dist[i - B] = (float)sqrt(a);
+}
+
+// backward.  grid (vblocks, BS): block handles voxels [vb*GT, +GT) and samples b = bs, bs+BS, ...
+//   part_dsig[bs][v], part_dgain[i][b][vb]
+__global__ void __launch_bounds__(GT)
+gam_bwd_k(const float* __restrict__ logits, const float* __restrict__ gain, const float* __restrict__ x,
+          const double* __restrict__ eps, const float* __restrict__ glm, const float* __restrict__ dist,
+          const float* __restrict__ g_slp, const float* __restrict__ g_dist, int C, int B, long long V,
+          float* __restrict__ d_logits, float* __restrict__ part_dsig, float* __restrict__ part_dgain) {
+    __shared__ float red[GT / VG_WAVE];
+    const int vb = blockIdx.x, bs = blockIdx.y, BS = gridDim.y, vblocks = gridDim.x;
+    const int lane = threadIdx.x % VG_WAVE, wave = threadIdx.x / VG_WAVE;
+    const long long v = (long long)vb * GT + threadIdx.x;
+    const bool ok = v < V;
+    const size_t BV = (size_t)B * V;
+    float sg = 1.f, inv_var = 1.f;
+    if (ok) { sg = (float)exp(-eps[v]); inv_var = 1.f / (sg * sg); }
+    float dsig = 0.f;
+    for (int b = bs; b < B; b += BS) {
+        // pass 1: reconstruction
+        float xr = 0.f;
+        if (ok) {
+            xr = sigmoidf_(logits[(size_t)b * V + v]);
+            for (int i = 1; i <= C; ++i)
+                xr += gain[(size_t)(i - 1) * B + b] * sigmoidf_(logits[(size_t)i * BV + (size_t)b * V + v]);
+        }
+        const float gs = g_slp[b];
+        float dxr = 0.f;
+        if (ok) {
+            const float r = x[(size_t)b * V + v] - xr;
+            dxr = gs * r * inv_var;                                    // d slp / d x_rec = r / sigma^2
+            dsig += gs * (r * r * inv_var / sg - 1.f / sg);            // d slp / d sigma
+            const float s0 = sigmoidf_(logits[(size_t)b * V + v]);
+            d_logits[(size_t)b * V + v] = dxr * s0 * (1.f - s0);
+        }
+        // pass 2: per covariate
+        for (int i = 1; i <= C; ++i) {
+            float dg = 0.f;
+            if (ok) {
+                const float gn = gain[(size_t)(i - 1) * B + b];
+                const float s = sigmoidf_(logits[(size_t)i * BV + (size_t)b * V + v]);
+                const float cons = gn * s;
+                const float dd = dist[(size_t)(i - 1) * B + b];
+                float dcons = dxr;
+                if (dd > 0.f) dcons += g_dist[(size_t)(i - 1) * B + b] * (cons - glm[(size_t)(i - 1) * V + v]) / dd;
+                dg = dcons * s;
+                d_logits[(size_t)i * BV + (size_t)b * V + v] = dcons * gn * s * (1.f - s);
+            }
+            dg = wsum(dg);
+            __syncthreads();
+            if (lane == 0) red[wave] = dg;
+            __syncthreads();
+            if (threadIdx.x == 0)
+                part_dgain[((size_t)(i - 1) * B + b) * vblocks + vb] = (red[0] + red[1]) + (red[2] + red[3]);
+        }
+    }
+    if (ok) part_dsig[(size_t)bs * V + v] = dsig;
+}
+
+__global__ void gam_bwd_fold_gain_k(const float* __restrict__ part_dgain, int CB, int vblocks, float* __restrict__ d_gain) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= CB) return;
+    double a = 0;
+    for (int k = 0; k < vblocks; ++k) a += part_dgain[(size_t)i * vblocks + k];
+    d_gain[i] = (float)a;
+}
+
+// d_eps[v] = dL/dsigma (fp32 sum over samples, cast to fp64) * dsigma/deps = -exp(-eps) (fp64)
+__global__ void gam_bwd_fold_eps_k(const float* __restrict__ part_dsig, const double* __restrict__ eps, int BS, long long V,
+                                   double* __restrict__ d_eps) {
+    const long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    float a = 0.f;
+    for (int k = 0; k < BS; ++k) a += part_dsig[(size_t)k * V + v];
+    d_eps[v] = (double)a * (-exp(-eps[v]));
+}
+
+int fwd_chunks(long long V) { return (int)((V + (long long)GT * GV - 1) / ((long long)GT * GV)); }
+int bwd_vblocks(long long V) { return (int)((V + GT - 1) / GT); }
+int bwd_bs(int B) { return B < 8 ? B : 8; }
+
+// ---------------------------------------------------------------------------------- Adam
+template <typename T>
+__global__ void __launch_bounds__(256)
+adam_k(T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m, T* __restrict__ v, long long n,
+       double b1, double b2, double eps, const double* __restrict__ sc) {
+    const T step_size = (T)sc[0], bc2_sqrt = (T)sc[1];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const T gi = g[i];
+        const T mi = m[i] + (gi - m[i]) * (T)(1.0 - b1);               // lerp_(grad, 1-beta1)
+        const T vi = v[i] * (T)b2 + (T)(1.0 - b2) * gi * gi;           // mul_(beta2).addcmul_(g, g, 1-beta2)
+        m[i] = mi; v[i] = vi;
+        const T denom = sqrt(vi) / bc2_sqrt + (T)eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t vg_gam_ws_bytes(int32_t C, int32_t B, int64_t V) {
+    if (C < 0 || C > GMAXC || B <= 0 || V <= 0) return -1;
+    const int64_t fwd = ((int64_t)B * fwd_chunks(V) + (int64_t)C * B * fwd_chunks(V)) * sizeof(float);
+    const int64_t bwd = ((int64_t)bwd_bs(B) * V + (int64_t)C * B * bwd_vblocks(V)) * sizeof(float);
+    return fwd > bwd ? fwd : bwd;
+}
+
+extern "C" int vg_gam_elbo_fwd(const float* logits, const float* gain, const float* x, const double* eps,
+                               const float* glm, int32_t C, int32_t B, int64_t V, void* ws,
+                               float* sum_log_prob, float* dist, float* maps_out, void* stream) {
+    if (!logits || !x || !eps || !ws || !sum_log_prob || (C > 0 && (!gain || !glm || !dist)) || C < 0 || C > GMAXC || B <= 0 ||
+        B > 65535 || V <= 0) {
+        vg_set_error("vg_gam_elbo_fwd: bad arguments C=%d B=%d V=%lld", C, B, (long long)V); return VG_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = fwd_chunks(V);
+    float* part_slp = (float*)ws;
+    float* part_d2 = part_slp + (size_t)B * chunks;
+    vg_launch(gam_fwd_k, dim3(chunks, B), dim3(GT), 0, s, logits, gain, x, eps, glm, (int)C, (int)B, (long long)V, part_slp, part_d2, maps_out);
+    int rc = vg_check_launch("gam_fwd");
+    if (rc) return rc;
+    vg_launch(gam_fwd_fold_k, dim3(vg_cdiv((C + 1) * B, 64)), dim3(64), 0, s, (const float*)part_slp, (const float*)part_d2,
+              (int)C, (int)B, chunks, sum_log_prob, dist);
+    return vg_check_launch("gam_fwd_fold");
+}
+
+extern "C" int vg_gam_elbo_bwd(const float* logits, const float* gain, const float* x, const double* eps,
+                               const float* glm, const float* dist, const float* g_slp, const float* g_dist,
+                               int32_t C, int32_t B, int64_t V, void* ws,
+                               float* d_logits, float* d_gain, double* d_eps, void* stream) {
+    if (!logits || !x || !eps || !ws || !g_slp || !d_logits || !d_eps || (C > 0 && (!gain || !glm || !dist || !g_dist || !d_gain)) ||
+        C < 0 || C > GMAXC || B <= 0 || V <= 0) {
+        vg_set_error("vg_gam_elbo_bwd: bad arguments C=%d B=%d V=%lld", C, B, (long long)V); return VG_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int vblocks = bwd_vblocks(V), BS = bwd_bs(B);
+    float* part_dsig = (float*)ws;
+    float* part_dgain = part_dsig + (size_t)BS * V;
+    vg_launch(gam_bwd_k, dim3(vblocks, BS), dim3(GT), 0, s, logits, gain, x, eps, glm, dist, g_slp, g_dist, (int)C, (int)B,
+              (long long)V, d_logits, part_dsig, part_dgain);
+    int rc = vg_check_launch("gam_bwd");
+    if (rc) return rc;
+    if (C > 0) {
+        vg_launch(gam_bwd_fold_gain_k, dim3(vg_cdiv(C * B, 64)), dim3(64), 0, s, (const float*)part_dgain, (int)(C * B), vblocks, d_gain);
+        if ((rc = vg_check_launch("gam_bwd_fold_gain"))) return rc;
+    }
+    vg_launch(gam_bwd_fold_eps_k, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, s, (const float*)part_dsig, eps, BS, (long long)V, d_eps);
+    return vg_check_launch("gam_bwd_fold_eps");
+}
+
+extern "C" int vg_adam_step(void* p, const void* g, void* m, void* v, int64_t n, int32_t is_f64,
+                            double b1, double b2, double eps, const double* step_scalars, void* stream) {
+    if (!p || !g || !m || !v || !step_scalars || n <= 0) { vg_set_error("vg_adam_step: bad arguments"); return VG_ERR_ARG; }
+    long long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t s = (hipStream_t)stream;
+    if (is_f64)
+        vg_launch(adam_k<double>, dim3((unsigned)blocks), dim3(256), 0, s, (double*)p, (const double*)g, (double*)m, (double*)v,
+                  (long long)n, b1, b2, eps, step_scalars);
+    else
+        vg_launch(adam_k<float>, dim3((unsigned)blocks), dim3(256), 0, s, (float*)p, (const float*)g, (float*)m, (float*)v,
+                  (long long)n, b1, b2, eps, step_scalars);
+    return vg_check_launch("adam");
+}

@@ -1,0 +1,319 @@
+"""Tensor-level operators over the HIP kernels (C ABI: include/vaegam.h).
+
+Every function takes torch tensors that already live where the library can reach them
+(HBM for libvaegam_hip.so), passes raw pointers + the current HIP stream, and allocates
+outputs/workspace through torch's caching allocator (so the whole train step can be captured
+into a hipGraph).  `BnConvAct` and `GamElbo` are the autograd nodes the model is built from;
+their backward passes are explicit kernel sequences, not autograd traces.
+
+Storage convention: a layer stores its PRE-activation output; the consumer applies the ReLU
+and the batch-norm affine while loading (`relu_in`, `gamma`/`beta`).  This removes every
+stand-alone ReLU / batch-norm-apply pass of the reference graph (vae_reg_GP.py:238-264).
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, WgradDesc
+
+BN_EPS = 1e-5            # nn.BatchNorm3d default (vae_reg_GP.py:194-196)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    if t.is_cuda:
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return None
+
+
+def _chk(t, dtype=torch.float32):
+    assert t.is_contiguous(), 'tensor must be contiguous'
+    assert t.dtype == dtype, 'expected %s, got %s' % (dtype, t.dtype)
+    return t
+
+
+# --------------------------------------------------------------------------- layer geometry
+@dataclass(frozen=True)
+class ConvSpec:
+    """One nn.Conv3d / nn.ConvTranspose3d of vae_reg_GP.py:189-215."""
+    kind: str                      # 'conv' | 'convt'
+    ci: int
+    co: int
+    k: Tuple[int, int, int]
+    stride: int
+    pad: Tuple[int, int, int] = (0, 0, 0)
+    outpad: Tuple[int, int, int] = (0, 0, 0)
+
+    def out_size(self, i):
+        if self.kind == 'conv':
+            return tuple((i[a] + 2 * self.pad[a] - self.k[a]) // self.stride + 1 for a in range(3))
+        return tuple((i[a] - 1) * self.stride - 2 * self.pad[a] + self.k[a] + self.outpad[a] for a in range(3))
+
+
+def pack_weight(w: torch.Tensor, spec: ConvSpec, direction: str) -> torch.Tensor:
+    """Repack a layer weight into the [ci_launch][tap][co_launch] order the kernels read through
+    the scalar path.  direction: 'fwd' (layer forward) or 'bwd' (data gradient)."""
+    fwd = direction == 'fwd'
+    if (spec.kind == 'conv') == fwd:
+        # conv forward / convT data-gradient: strided correlation with the weight as stored
+        # conv w[co][ci][k] -> [ci][k][co];   convT w[ci][co][k] (launch ci=co_l, co=ci_l) -> [co_l][k][ci_l]
+        return w.permute(1, 2, 3, 4, 0).contiguous()
+    # convT forward / conv data-gradient: transposed form.  stride 1 runs as a correlation with the
+    # kernel flipped; stride 2 runs in gather form with the kernel as stored.
+    if spec.stride == 1:
+        w = w.flip(2, 3, 4)
+    return w.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _conv_desc(N, ci, co, isz, osz, k, stride, pad, relu_in, per_group):
+    return ConvDesc(N, ci, co, isz[0], isz[1], isz[2], osz[0], osz[1], osz[2], k[0], k[1], k[2], stride,
+                    pad[0], pad[1], pad[2], int(relu_in), int(per_group))
+
+
+def conv_forward(x, wpk, bias, spec: ConvSpec, relu_in=False, scale=None, shift=None, per_group=1):
+    """Layer forward: y = conv/convT(P(x)) + bias, y is the pre-activation."""
+    lib = _lib.get_lib()
+    N = x.shape[0]
+    isz = tuple(x.shape[2:]); osz = spec.out_size(isz)
+    y = torch.empty((N, spec.co) + osz, dtype=torch.float32, device=x.device)
+    _chk(x); _chk(wpk)
+    if spec.kind == 'conv':
+        assert spec.pad == (0, 0, 0)
+        d = _conv_desc(N, spec.ci, spec.co, isz, osz, spec.k, spec.stride, (0, 0, 0), relu_in, per_group)
+        lib.call('vg_corr3d', ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(scale), _p(shift), None, _p(y), _stream(x))
+    elif spec.stride == 1:
+        padc = tuple(spec.k[a] - 1 - spec.pad[a] for a in range(3))
+        d = _conv_desc(N, spec.ci, spec.co, isz, osz, spec.k, 1, padc, relu_in, per_group)
+        lib.call('vg_corr3d', ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(scale), _p(shift), None, _p(y), _stream(x))
+    else:
+        d = _conv_desc(N, spec.ci, spec.co, isz, osz, spec.k, 2, spec.pad, relu_in, per_group)
+        lib.call('vg_tconv3d_s2', ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(scale), _p(shift), None, _p(y), _stream(x))
+    return y
+
+
+def conv_backward_data(dy, wpk_bwd, spec: ConvSpec, in_size, mask_src=None):
+    """Gradient w.r.t. the layer's (post-prologue) input; `mask_src` fuses the producer's ReLU backward."""
+    lib = _lib.get_lib()
+    N = dy.shape[0]
+    osz = tuple(dy.shape[2:]); isz = tuple(in_size)
+    dx = torch.empty((N, spec.ci) + isz, dtype=torch.float32, device=dy.device)
+    _chk(dy); _chk(wpk_bwd)
+    if spec.kind == 'convt':
+        # dx[i] = sum_k dy[i*s - pad + k] w[k]: strided correlation over dy
+        d = _conv_desc(N, spec.co, spec.ci, osz, isz, spec.k, spec.stride, spec.pad, False, 1)
+        lib.call('vg_corr3d', ctypes.byref(d), _p(dy), _p(wpk_bwd), None, None, None, _p(mask_src), _p(dx), _stream(dy))
+    elif spec.stride == 1:
+        padc = tuple(spec.k[a] - 1 for a in range(3))
+        d = _conv_desc(N, spec.co, spec.ci, osz, isz, spec.k, 1, padc, False, 1)
+        lib.call('vg_corr3d', ctypes.byref(d), _p(dy), _p(wpk_bwd), None, None, None, _p(mask_src), _p(dx), _stream(dy))
+    else:
+        d = _conv_desc(N, spec.co, spec.ci, osz, isz, spec.k, 2, (0, 0, 0), False, 1)
+        lib.call('vg_tconv3d_s2', ctypes.byref(d), _p(dy), _p(wpk_bwd), None, None, None, _p(mask_src), _p(dx), _stream(dy))
+    return dx
+
+
+def conv_weight_grad(x, dy, spec: ConvSpec, relu_in=False, scale=None, shift=None, per_group=1):
+    """dL/dW in the layer's own weight layout; the prologue of the forward is re-applied to x on load."""
+    lib = _lib.get_lib()
+    N = x.shape[0]
+    isz = tuple(x.shape[2:]); osz = tuple(dy.shape[2:])
+    _chk(x); _chk(dy)
+    if spec.kind == 'conv':
+        d = WgradDesc(N, spec.co, spec.ci, *osz, *isz, *spec.k, spec.stride, 0, 0, 0, 1, int(relu_in), int(per_group))
+        a, b = x, dy
+        shape = (spec.co, spec.ci) + tuple(spec.k)
+    else:
+        d = WgradDesc(N, spec.ci, spec.co, *isz, *osz, *spec.k, spec.stride, *spec.pad, 0, int(relu_in), int(per_group))
+        a, b = dy, x
+        shape = (spec.ci, spec.co) + tuple(spec.k)
+    nbytes = lib.size('vg_wgrad3d_ws_bytes', ctypes.byref(d))
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
+    dw = torch.empty(shape, dtype=torch.float32, device=x.device)
+    lib.call('vg_wgrad3d', ctypes.byref(d), _p(a), _p(b), _p(scale), _p(shift), _p(ws), _p(dw), _stream(x))
+    return dw
+
+
+# --------------------------------------------------------------------------- batch norm pieces
+def _bn_ws(x, N, C, P, per_group):
+    nbytes = _lib.get_lib().size('vg_bn_ws_bytes', N, C, P, per_group)
+    return torch.empty(nbytes // 8, dtype=torch.float64, device=x.device)
+
+
+def bn_stats(x, gamma, beta, relu, per_group, sync=None):
+    """Batch statistics of relu?(x) per (group, channel) -> (scale, shift, mean, rstd), each [G*C].
+    `sync(t)` (optional) all-reduces the raw [sum, sumsq, count] triples across data-parallel ranks."""
+    lib = _lib.get_lib()
+    N, C = x.shape[0], x.shape[1]
+    P = x[0, 0].numel()
+    G = N // per_group
+    ws = _bn_ws(x, N, C, P, per_group)
+    out = torch.empty((4, G * C), dtype=torch.float32, device=x.device)
+    if sync is None:
+        lib.call('vg_bn_stats', _p(_chk(x)), N, C, P, per_group, int(relu), _p(gamma), _p(beta), BN_EPS, _p(ws), None,
+                 _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _stream(x))
+    else:
+        sums = torch.empty((G * C, 3), dtype=torch.float64, device=x.device)
+        lib.call('vg_bn_stats', _p(_chk(x)), N, C, P, per_group, int(relu), _p(gamma), _p(beta), BN_EPS, _p(ws), _p(sums),
+                 None, None, None, None, _stream(x))
+        sums = sync(sums)
+        lib.call('vg_bn_finalize', _p(sums), G, C, _p(gamma), _p(beta), BN_EPS, _p(out[0]), _p(out[1]), _p(out[2]),
+                 _p(out[3]), _stream(x))
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_backward_(dxe, p, gamma, mean, rstd, relu, per_group, sync=None):
+    """In place: dxe (grad w.r.t. the normalised tensor) -> grad w.r.t. the stored pre-activation p.
+    Returns (dgamma[C], dbeta[C]) summed over groups."""
+    lib = _lib.get_lib()
+    N, C = p.shape[0], p.shape[1]
+    P = p[0, 0].numel()
+    G = N // per_group
+    ws = _bn_ws(p, N, C, P, per_group)
+    sums = torch.empty((G * C, 2), dtype=torch.float64, device=p.device)
+    lib.call('vg_bn_bwd_reduce', _p(_chk(dxe)), _p(_chk(p)), N, C, P, per_group, int(relu), _p(mean), _p(rstd), _p(ws),
+             _p(sums), _stream(p))
+    count = float(per_group * P)
+    if sync is not None:
+        sums = sync(sums)
+        count = count * sync.world_size
+    parts = torch.empty((2, G, C), dtype=torch.float32, device=p.device)
+    lib.call('vg_bn_bwd_apply', _p(dxe), _p(p), N, C, P, per_group, int(relu), _p(gamma), _p(mean), _p(rstd), _p(sums),
+             count, _p(parts[0]), _p(parts[1]), _stream(p))
+    return parts[0].sum(0), parts[1].sum(0)
+
+
+def channel_sum(x):
+    lib = _lib.get_lib()
+    N, C = x.shape[0], x.shape[1]
+    P = x[0, 0].numel()
+    ws = _bn_ws(x, N, C, P, N)
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    lib.call('vg_channel_sum', _p(_chk(x)), N, C, P, _p(ws), _p(out), _stream(x))
+    return out
+
+
+# --------------------------------------------------------------------------- autograd nodes
+class BnConvAct(torch.autograd.Function):
+    """y = conv( BN( relu?(p_in) ) ) + bias, everything stored pre-activation.
+
+    forward  : [bn_stats] -> corr3d / tconv3d_s2 with the ReLU + affine applied while staging tiles
+    backward : channel_sum (bias), wgrad3d, data gradient (+ fused ReLU mask), [bn backward]
+    `input_is_data=True` (first encoder layer): no data gradient is formed; the batch-norm
+    parameter gradients follow from the weight gradient (valid conv, every tap hits the input).
+    """
+
+    @staticmethod
+    def forward(ctx, p_in, weight, bias, gamma, beta, spec: ConvSpec, relu_in: bool, per_group: int,
+                input_is_data: bool, sync):
+        p_in = p_in.contiguous()
+        has_bn = gamma is not None
+        scale = shift = mean = rstd = None
+        if has_bn:
+            scale, shift, mean, rstd = bn_stats(p_in, gamma, beta, relu_in, per_group, sync)
+        y = conv_forward(p_in, pack_weight(weight, spec, 'fwd'), bias, spec, relu_in, scale, shift, per_group)
+        ctx.spec, ctx.relu_in, ctx.per_group, ctx.input_is_data, ctx.sync, ctx.has_bn = \
+            spec, relu_in, per_group, input_is_data, sync, has_bn
+        ctx.save_for_backward(p_in, weight, gamma, beta, scale, shift, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p_in, weight, gamma, beta, scale, shift, mean, rstd = ctx.saved_tensors
+        spec, relu_in, per_group = ctx.spec, ctx.relu_in, ctx.per_group
+        dy = dy.contiguous()
+        db = channel_sum(dy)
+        dgamma = dbeta = dp = None
+        if ctx.input_is_data:
+            if ctx.has_bn:
+                assert spec.kind == 'conv' and spec.pad == (0, 0, 0) and not relu_in
+                G = p_in.shape[0] // per_group
+                assert G == 1
+                # weight gradient against the NORMALISED input xhat = (x-mean)*rstd, then
+                #   dw = gamma*dw_hat + beta*db ;  dgamma = <w, dw_hat> ; dbeta = <sum_k w, db>
+                dw_hat = conv_weight_grad(p_in, dy, spec, False, rstd, -mean * rstd, per_group)
+                g5 = gamma.view(1, -1, 1, 1, 1); b5 = beta.view(1, -1, 1, 1, 1)
+                dw = g5 * dw_hat + b5 * db.view(-1, 1, 1, 1, 1)
+                dgamma = (weight * dw_hat).sum((0, 2, 3, 4))
+                dbeta = (weight.sum((2, 3, 4)) * db.view(-1, 1)).sum(0)
+            else:
+                dw = conv_weight_grad(p_in, dy, spec, relu_in, None, None, per_group)
+            return None, dw, db, dgamma, dbeta, None, None, None, None, None
+        dw = conv_weight_grad(p_in, dy, spec, relu_in, scale, shift, per_group)
+        wb = pack_weight(weight, spec, 'bwd')
+        in_size = tuple(p_in.shape[2:])
+        if ctx.has_bn:
+            dp = conv_backward_data(dy, wb, spec, in_size, None)
+            dgamma, dbeta = bn_backward_(dp, p_in, gamma, mean, rstd, relu_in, per_group, ctx.sync)
+        else:
+            dp = conv_backward_data(dy, wb, spec, in_size, p_in if relu_in else None)
+        return dp, dw, db, dgamma, dbeta, None, None, None, None, None
+
+
+def bn_conv_act(p_in, weight, bias, gamma, beta, spec, relu_in, per_group=None, input_is_data=False, sync=None):
+    if per_group is None:
+        per_group = p_in.shape[0]
+    return BnConvAct.apply(p_in, weight, bias, gamma, beta, spec, relu_in, per_group, input_is_data, sync)
+
+
+class GamElbo(torch.autograd.Function):
+    """(logits[G,B,V], gain[C,B], x[B,V], eps[V] f64, glm[C,V]) -> (sum_log_prob[B], dist[C,B])."""
+
+    @staticmethod
+    def forward(ctx, logits, gain, x, eps, glm):
+        lib = _lib.get_lib()
+        G, B, V = logits.shape
+        C = G - 1
+        logits = _chk(logits.contiguous()); gain = _chk(gain.contiguous()); x = _chk(x.contiguous())
+        eps = _chk(eps.contiguous(), torch.float64); glm = _chk(glm.contiguous())
+        ws = torch.empty(lib.size('vg_gam_ws_bytes', C, B, V) // 4 + 1, dtype=torch.float32, device=x.device)
+        slp = torch.empty(B, dtype=torch.float32, device=x.device)
+        dist = torch.empty((C, B), dtype=torch.float32, device=x.device)
+        lib.call('vg_gam_elbo_fwd', _p(logits), _p(gain), _p(x), _p(eps), _p(glm), C, B, V, _p(ws), _p(slp), _p(dist),
+                 None, _stream(x))
+        ctx.save_for_backward(logits, gain, x, eps, glm, dist)
+        return slp, dist
+
+    @staticmethod
+    def backward(ctx, g_slp, g_dist):
+        lib = _lib.get_lib()
+        logits, gain, x, eps, glm, dist = ctx.saved_tensors
+        G, B, V = logits.shape
+        C = G - 1
+        g_slp = _chk(g_slp.contiguous()); g_dist = _chk(g_dist.contiguous())
+        ws = torch.empty(lib.size('vg_gam_ws_bytes', C, B, V) // 4 + 1, dtype=torch.float32, device=x.device)
+        d_logits = torch.empty_like(logits)
+        d_gain = torch.empty_like(gain)
+        d_eps = torch.empty_like(eps)
+        lib.call('vg_gam_elbo_bwd', _p(logits), _p(gain), _p(x), _p(eps), _p(glm), _p(dist), _p(g_slp), _p(g_dist),
+                 C, B, V, _p(ws), _p(d_logits), _p(d_gain), _p(d_eps), _stream(x))
+        return d_logits, d_gain, None, d_eps, None
+
+
+def gam_maps(logits, gain, x, eps, glm):
+    """Reconstruction path (vae_reg_GP.py:331,391-392): the C+2 maps [base, cons_1..C, full_rec] as [C+2,B,V]."""
+    lib = _lib.get_lib()
+    G, B, V = logits.shape
+    C = G - 1
+    ws = torch.empty(lib.size('vg_gam_ws_bytes', C, B, V) // 4 + 1, dtype=torch.float32, device=x.device)
+    slp = torch.empty(B, dtype=torch.float32, device=x.device)
+    dist = torch.empty((max(C, 1), B), dtype=torch.float32, device=x.device)
+    maps = torch.empty((G + 1, B, V), dtype=torch.float32, device=x.device)
+    lib.call('vg_gam_elbo_fwd', _p(_chk(logits.contiguous())), _p(_chk(gain.contiguous())), _p(_chk(x.contiguous())),
+             _p(_chk(eps.contiguous(), torch.float64)), _p(_chk(glm.contiguous())), C, B, V, _p(ws), _p(slp), _p(dist),
+             _p(maps), _stream(x))
+    return maps
+
+
+def adam_step_(p, g, m, v, b1, b2, eps, step_scalars):
+    """In-place fused Adam over one flat buffer (fp32 or fp64)."""
+    lib = _lib.get_lib()
+    assert p.dtype == g.dtype == m.dtype == v.dtype and p.dtype in (torch.float32, torch.float64)
+    assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+    lib.call('vg_adam_step', _p(p), _p(g), _p(m), _p(v), p.numel(), int(p.dtype == torch.float64), float(b1), float(b2),
+             float(eps), _p(_chk(step_scalars, torch.float64)), _stream(p))
