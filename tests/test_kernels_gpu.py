@@ -1,0 +1,69 @@
+"""HIP kernels (libvaegam_hip.so, through the C ABI) against plain PyTorch fp32 references on
+the GPU box: the shrunk per-layer cases of tests/kernel_cases.py plus every layer at the
+reference's real 41x49x35 geometry."""
+import numpy as np
+import pytest
+import torch
+
+import vae_gam_amd  # noqa: F401
+from vae_gam_amd import _lib, ops
+import kernel_cases as K
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module', autouse=True)
+def hip_lib():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    _lib.set_library_for_tests(None)
+    lib = _lib.get_lib()                       # raises if libvaegam_hip.so is missing: no fallback
+    assert lib.path.endswith('libvaegam_hip.so')
+    yield
+
+
+@pytest.mark.parametrize('name,spec,isz', K.LAYERS, ids=[l[0] for l in K.LAYERS])
+def test_layer_bn_relu(name, spec, isz):
+    K.run_layer_case('cuda', name, spec, isz, with_bn=True, relu_in=(name != 'conv1'), groups=2 if spec.kind == 'convt' else 1)
+
+
+@pytest.mark.parametrize('name,spec,isz', [K.LAYERS[1], K.LAYERS[3], K.LAYERS[6], K.LAYERS[8]], ids=['conv2', 'conv4', 'convt2', 'convt4'])
+def test_layer_relu_only(name, spec, isz):
+    K.run_layer_case('cuda', name, spec, isz, with_bn=False, relu_in=True, groups=1, seed=3)
+
+
+def test_first_layer_input_is_data():
+    name, spec, isz = K.LAYERS[0]
+    K.run_layer_case('cuda', name, spec, isz, with_bn=True, relu_in=False, groups=1, input_is_data=True, seed=5)
+
+
+# the reference's real layer geometry (vae_reg_GP.py:187-218)
+FULL = [(41, 49, 35), (39, 47, 33), (19, 23, 16), (17, 21, 14), (8, 10, 6), (6, 8, 5), (8, 10, 7), (16, 21, 14),
+        (18, 23, 16), (39, 47, 33)]
+
+
+@pytest.mark.parametrize('idx', range(10), ids=[l[0] for l in K.LAYERS])
+def test_layer_full_geometry(idx):
+    name, spec, _ = K.LAYERS[idx]
+    K.run_layer_case('cuda', name + '_full', spec, FULL[idx], with_bn=idx in (0, 2, 4, 5, 7, 9), relu_in=(idx != 0),
+                     groups=2 if spec.kind == 'convt' else 1, seed=7 + idx, tol=5e-4)
+
+
+def test_gam_elbo():
+    K.run_gam_case('cuda', C=3, B=3, V=1500)
+    K.run_gam_case('cuda', C=8, B=4, V=70315, seed=4)
+
+
+def test_gam_elbo_no_covariates():
+    K.run_gam_case('cuda', C=0, B=2, V=700, seed=2)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_adam(dtype):
+    K.run_adam_case('cuda', dtype, n=200000)
+
+
+def test_library_refuses_bad_shapes():
+    spec = ops.ConvSpec('conv', 8, 4, (3, 3, 3), 1)                  # CO=4 has no kernel instance
+    x = torch.zeros(1, 8, 5, 5, 5, device='cuda'); w = torch.zeros(4, 8, 3, 3, 3, device='cuda')
+    with pytest.raises(_lib.VgError):
+        ops.conv_forward(x, ops.pack_weight(w, spec, 'fwd'), None, spec)
