@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE: oracle outputs at sizes that are too slow to recompute inside the GPU tests.
+
+Runs the CPU oracle (fp32 = the reference's arithmetic, and the same algorithm in float64 as a
+conditioning yardstick) on the BASELINE config-2 shape (batch 32, 3 covariates, synthetic checker
+set) and stores what tests/test_model_gpu.py compares against: loss terms, gains, and for every
+parameter the gradient norm, the fp32-vs-fp64 distance and up to 512 sampled entries.
+Weights come from the product's seeded initialiser, inputs from vae_gam_amd.synthetic (both are
+recipes: only seeds travel).   Usage: python oracle/gen_oracle_fixtures.py
+"""
+import os
+import sys
+import time
+import zlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE); sys.path.insert(0, ROOT)
+import bridge  # noqa: E402
+import vaegam_oracle as O  # noqa: E402
+import vae_gam_amd  # noqa: E402,F401
+from vae_gam_amd import synthetic  # noqa: E402
+from vae_gam_amd.vae_reg_GP import VAE  # noqa: E402
+
+
+def case_inputs(B=32, C=3, data_seed=3, noise_seed=5, model_seed=1, device='cpu'):
+    ds = synthetic.make_dataset(num_subjects=2, vols_per_subject=20, num_covariates=C, seed=data_seed)
+    torch.manual_seed(model_seed)
+    model = VAE(num_covariates=C, glm_maps=ds['glm'], xu_ranges=ds['xu_ranges'], device_name=device)
+    x = torch.from_numpy(ds['volumes'][:B]); cov = torch.from_numpy(ds['covariates'][:B])
+    cfg = bridge.oracle_config(model)
+    noise = O.draw_noise(B, cfg, torch.Generator().manual_seed(noise_seed))
+    return ds, model, cfg, x, cov, noise
+
+
+def sample_idx(name, n, k=512):
+    r = np.random.Generator(np.random.PCG64(zlib.crc32(name.encode())))
+    return np.sort(r.choice(n, min(k, n), replace=False))
+
+
+def main():
+    torch.set_num_threads(os.cpu_count() or 1)
+    ds, model, cfg, x, cov, noise = case_inputs()
+    params = bridge.params_from_model(model)
+    glm = torch.from_numpy(ds['glm'])
+    t = time.time()
+    out32, g32 = O.loss_and_grads(params, cfg, x, cov, glm, noise)
+    print('fp32 oracle %.1fs' % (time.time() - t), flush=True)
+    t = time.time()
+    p64, x64, c64, n64 = O.to_float64(params, x, cov, noise)
+    out64, g64 = O.loss_and_grads(p64, cfg, x64, c64, glm, n64)
+    print('fp64 oracle %.1fs' % (time.time() - t), flush=True)
+    arr = {'loss32': out32['loss'].detach().numpy(), 'loss64': out64['loss'].detach().numpy(),
+           'slp32': out32['sum_log_prob'].detach().numpy(), 'z32': out32['z'].detach().numpy(),
+           'kl_z32': out32['kl_z'].detach().numpy(), 'gp_kl32': out32['gp_kl_loss'].detach().numpy(),
+           'glm_reg32': out32['glm_reg'].detach().numpy()}
+    for c in cfg.schema:
+        arr['task_var32.' + c.name] = out32['task_var'][c.name].detach().numpy()
+        arr['task_var64.' + c.name] = out64['task_var'][c.name].detach().numpy()
+    for k in g32:
+        if g32[k] is None:
+            continue
+        a32 = g32[k].double().flatten().numpy(); a64 = g64[k].flatten().numpy()
+        idx = sample_idx(k, a64.size)
+        arr['g.%s.norm64' % k] = np.sqrt((a64 * a64).sum())
+        arr['g.%s.dist32_64' % k] = np.sqrt(((a32 - a64) ** 2).sum())
+        arr['g.%s.idx' % k] = idx
+        arr['g.%s.val64' % k] = a64[idx]
+        arr['g.%s.val32' % k] = a32[idx]
+    out = os.path.join(ROOT, 'tests', 'golden', 'oracle_B32_C3.npz')
+    np.savez_compressed(out, **arr)
+    print('wrote', out, os.path.getsize(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -283,7 +283,7 @@ def do_hrf_conv(task_var: torch.Tensor) -> torch.Tensor:
     via the (B, B+14) Toeplitz matrix the reference builds (hrf cast to fp32 on assignment)."""
     hk = torch.tensor(hrf_kernel())
     B, T = task_var.shape[0], hk.shape[0]
-    shifted = torch.zeros((B, B + T - 1))
+    shifted = torch.zeros((B, B + T - 1), dtype=task_var.dtype)
     for i in range(B):
         shifted[i, i:i + T] = hk
     out = torch.mm(task_var.unsqueeze(0), shifted)
@@ -324,10 +324,10 @@ def gp_posterior(xu: torch.Tensor, k_var, ls, qu_m, qu_S, xq: torch.Tensor):
     n = xu.shape[0]
     step = (xu[1] - xu[0]).detach()
     d0 = (xu[0].detach().double() - xq.detach().double())                 # float(...) per query point
-    knu_d = (d0.unsqueeze(0) + torch.arange(n, dtype=torch.float64).unsqueeze(1) * step.double()).float()
+    knu_d = (d0.unsqueeze(0) + torch.arange(n, dtype=torch.float64).unsqueeze(1) * step.double()).to(xq.dtype)
     knu = gp_kernel(knu_d, k_var, ls)                                      # (n, B)
     knn = gp_kernel(xq.unsqueeze(0) - xq.unsqueeze(1), k_var, ls)          # knn[i,:] = xq - xq[i]
-    idx = torch.arange(n, dtype=torch.get_default_dtype())
+    idx = torch.arange(n, dtype=xq.dtype)
     ku = gp_kernel((idx.unsqueeze(0) - idx.unsqueeze(1)).abs(), k_var, ls, step)
     A = knu.T @ torch.inverse(ku)
     f_bar = A @ torch.squeeze(qu_m)
@@ -366,6 +366,7 @@ def forward(p: Dict[str, torch.Tensor], cfg: OracleConfig, x: torch.Tensor, cova
     Returns a dict with 'loss' (shape (1,)) and every intermediate the parity tests compare.
     """
     B, C = x.shape[0], cfg.num_covariates
+    dt = x.dtype                      # fp32 = the reference; fp64 (all inputs/params cast) = conditioning yardstick
     out: Dict[str, object] = {}
     mu, u, d = encode(p, cfg, x, reduce_fn)
     if bool((d < 1e-6).any()):                                           # :321-323
@@ -374,15 +375,15 @@ def forward(p: Dict[str, torch.Tensor], cfg: OracleConfig, x: torch.Tensor, cova
     out.update(mu=mu, u=u, d=d, z=z, kl_z=kl_z)
 
     def onehot(i):
-        oh = torch.zeros(B, C + 1); oh[:, i] = 1.0
+        oh = torch.zeros(B, C + 1, dtype=dt); oh[:, i] = 1.0
         return torch.cat([z, oh], 1)
 
     x_rec = decode(p, cfg, onehot(0), reduce_fn)                         # :326-330
     maps = {'base': x_rec}
-    gp_kl_loss = torch.zeros(1)
-    glm_reg = torch.zeros(())
+    gp_kl_loss = torch.zeros(1, dtype=dt)
+    glm_reg = torch.zeros((), dtype=dt)
     f_bars, Sigmas, task_vars, beta_means, beta_covs = {}, {}, {}, {}, {}
-    eyeB = torch.eye(B)
+    eyeB = torch.eye(B, dtype=dt)
     for i, cov in enumerate(cfg.schema, start=1):                        # :338
         diff = decode(p, cfg, onehot(i), reduce_fn)                      # :339-343
         xq = covariates[:, i - 1]
@@ -407,7 +408,7 @@ def forward(p: Dict[str, torch.Tensor], cfg: OracleConfig, x: torch.Tensor, cova
             task_var = do_hrf_conv(task_var)
         task_vars[cov.name] = task_var
         cons = torch.einsum('b,bx->bx', task_var, diff)                  # :380
-        g = glm_maps[:, i].float()
+        g = glm_maps[:, i].to(dt)
         if cfg.glm_cdist:
             glm_reg = glm_reg + torch.sum(torch.cdist(cons, g.unsqueeze(0).expand(B, -1), p=2))  # :388
         else:
@@ -418,7 +419,7 @@ def forward(p: Dict[str, torch.Tensor], cfg: OracleConfig, x: torch.Tensor, cova
             maps[cov.name] = cons
     maps['full_rec'] = x_rec
     # ELBO (:400-408)
-    scale = torch.exp(-p['epsilon'].reshape(1, -1).expand(B, -1)).float()
+    scale = torch.exp(-p['epsilon'].reshape(1, -1).expand(B, -1)).to(dt)
     xf = x.reshape(B, -1)
     log_prob = -((xf - x_rec) ** 2) / (2 * scale ** 2) - scale.log() - math.log(math.sqrt(2 * math.pi))
     sum_log_prob = log_prob.sum(1)
@@ -461,6 +462,13 @@ class AdamState:
             bc1, bc2 = 1 - self.b1 ** t, 1 - self.b2 ** t
             denom = (self.v[k].sqrt() / math.sqrt(bc2)).add_(self.eps)
             params[k].addcdiv_(self.m[k], denom, value=-(self.lr / bc1))
+
+
+def to_float64(params, x, covariates, noise):
+    """Everything cast to float64: the same algorithm evaluated without fp32 rounding, used by the
+    tests to size the reference's own fp32 conditioning."""
+    return ({k: v.double() for k, v in params.items()}, x.double(), covariates.double(),
+            {k: v.double() for k, v in noise.items()})
 
 
 def loss_and_grads(params, cfg, x, covariates, glm_maps, noise, reduce_fn=None, batch_scale=None):

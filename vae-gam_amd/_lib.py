@@ -73,6 +73,7 @@ class VgLibrary:
 
 
 _LIB = None
+_INJECTED = False
 
 
 def library_path():
@@ -88,5 +89,10 @@ def get_lib() -> VgLibrary:
 
 def set_library_for_tests(lib):
     """tests only: inject a handle (e.g. the host build of the kernels under tests/emu)."""
-    global _LIB
+    global _LIB, _INJECTED
     _LIB = lib
+    _INJECTED = lib is not None
+
+
+def test_library_injected():
+    return _INJECTED

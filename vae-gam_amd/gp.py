@@ -35,15 +35,21 @@ def posterior_batched(xu, k_var, ls, qu_m, qu_S, xq):
     step = (xu[:, 1] - xu[:, 0]).detach()
     d0 = xu[:, 0].detach().double().unsqueeze(1) - xq.detach().double()                    # (K,B)
     kidx = torch.arange(n, device=xu.device, dtype=torch.float64)
-    knu_d = (d0.unsqueeze(1) + kidx.view(1, n, 1) * step.double().view(K, 1, 1)).float()   # (K,n,B)
+    knu_d = (d0.unsqueeze(1) + kidx.view(1, n, 1) * step.double().view(K, 1, 1)).float().to(xq.dtype)   # (K,n,B); fp32-rounded as gp.py:90
     kv, l_ = k_var.view(K, 1, 1), ls.view(K, 1, 1)
-    knu = distance_to_kernel(knu_d, kv, l_)
-    knn = distance_to_kernel(xq.unsqueeze(1) - xq.unsqueeze(2), kv, l_)                     # [k,i,j] = xq_j - xq_i
-    ku = distance_to_kernel(striped_matrix(n, xu.device).unsqueeze(0) * step.view(K, 1, 1), kv, l_)
-    ku_inv = torch.linalg.inv_ex(ku, check_errors=False).inverse
-    A = knu.transpose(1, 2) @ ku_inv                                                        # (K,B,n)
+    one = torch.ones((), device=xu.device, dtype=xq.dtype)
+    step = step.to(xq.dtype)
+    # A = Knu^T Ku^-1 does not depend on the kernel variance (it cancels).  The reference lets autograd
+    # differentiate both factors and sums two large cancelling terms into d/d(k_var), which in fp32 is
+    # pure rounding noise at batch 32 (tests/test_model_gpu.py); building A from UNIT-variance kernels
+    # keeps the forward value (same products up to one rounding) and removes that cancellation.
+    knu1 = distance_to_kernel(knu_d, one, l_)
+    knn1 = distance_to_kernel(xq.unsqueeze(1) - xq.unsqueeze(2), one, l_)                   # [k,i,j] = xq_j - xq_i
+    ku1 = distance_to_kernel(striped_matrix(n, xu.device, xq.dtype).unsqueeze(0) * step.view(K, 1, 1), one, l_)
+    ku1_inv = torch.linalg.inv_ex(ku1, check_errors=False).inverse
+    A = knu1.transpose(1, 2) @ ku1_inv                                                      # (K,B,n)
     f_bar = (A @ qu_m.unsqueeze(-1)).squeeze(-1)
-    Sigma = knn + A @ (qu_S - ku) @ A.transpose(1, 2)
+    Sigma = kv * knn1 + A @ (qu_S - kv * ku1) @ A.transpose(1, 2)
     return f_bar, Sigma
 
 

@@ -1,0 +1,69 @@
+"""Host-side helpers of the hot path (drop-in for the reference's utils.py:22-73) plus the
+pieces of its preprocessing the synthetic generator restates (utils.py:93-123, 170-178)."""
+import argparse
+
+import numpy as np
+
+
+def hrf(times):
+    """Double-gamma haemodynamic response, peak-normalised to 0.6 (utils.py:22-36)."""
+    from scipy.stats import gamma
+    times = np.asarray(times, dtype=np.float64)
+    values = gamma.pdf(times, 6) - 0.35 * gamma.pdf(times, 12)
+    return values / np.max(values) * 0.6
+
+
+def get_xu_ranges(csv_files, eps=1e-3):
+    """[min-eps, max+eps] of each motion regressor over train and test CSVs (utils.py:39-56)."""
+    import pandas as pd
+    frames = [pd.read_csv(f) for f in csv_files[:2]]
+    out = []
+    for reg in ['x', 'y', 'z', 'rot_x', 'rot_y', 'rot_z']:
+        lo = min(float(df[reg].min()) for df in frames)
+        hi = max(float(df[reg].max()) for df in frames)
+        out.append([lo - eps, hi + eps])
+    return out
+
+
+def str2bool(v):
+    """argparse bool flag parser (utils.py:59-73; the reference forgets to import argparse)."""
+    if isinstance(v, bool):
+        return v
+    s = str(v).lower()
+    if s in ('yes', 'true', 't', 'y', '1'):
+        return True
+    if s in ('no', 'false', 'f', 'n', '0'):
+        return False
+    raise argparse.ArgumentTypeError('Boolean value expected.')
+
+
+def control_stimulus_to_neural(vol_times, block=20.0):
+    """Block design of the control experiments: ON during even 20-s blocks, starting ON (utils.py:93-111)."""
+    t = np.asarray(vol_times) // block
+    return (t.astype(np.int64) % 2 == 0).astype(np.int64)
+
+
+def zscore_columns(a):
+    """Column-wise z-score with population std (utils.py:113-123)."""
+    a = np.asarray(a, dtype=np.float64)
+    return (a - a.mean(0)) / a.std(0)
+
+
+def scale_beta_maps(beta_maps):
+    """Divide each map (row) by its maximum (utils.py:170-178)."""
+    beta_maps = np.array(beta_maps, dtype=np.float64, copy=True)
+    return beta_maps / beta_maps.max(1, keepdims=True)
+
+
+def log_map(writer, img_shape, maps, slice_idx, tag, batch_size, log_type):
+    """Axial slice of every batch element to the writer (subset of utils.py:373-389; opt-in)."""
+    add = getattr(writer, 'add_images', None)
+    if add is None:
+        return
+    try:
+        import torch
+        m = maps.detach().reshape(batch_size, *img_shape)[:, :, :, slice_idx] if isinstance(maps, torch.Tensor) \
+            else np.asarray(maps).reshape(batch_size, *img_shape)[:, :, :, slice_idx]
+        add('%s_%s_slice_%d' % (tag, log_type, slice_idx), m[:, None], dataformats='NCHW')
+    except Exception:
+        pass

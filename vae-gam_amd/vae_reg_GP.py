@@ -1,0 +1,493 @@
+"""VAE-GAM model on the MI355X-native kernels -- drop-in surface of the reference's vae_reg_GP.py.
+
+Same constructor arguments, methods, attributes, checkpoint dictionary and (seeded) initial
+parameters as the reference's `VAE` (vae_reg_GP.py:35-185, 236-264, 307-539, 691-715), but the
+train step runs on hand-written HIP kernels through the C ABI of include/vaegam.h:
+
+  * the C+1 decoder calls of one forward (vae_reg_GP.py:330,343) run as ONE batched launch per
+    layer over (C+1)*B samples with batch-norm statistics kept per variant;
+  * activations are stored pre-activation, ReLU / batch-norm affine are applied by the consuming
+    conv kernel while it stages its LDS tile, ReLU backward is fused into the data-gradient epilogue;
+  * effect-map scaling, accumulation, Gaussian log-likelihood and the GLM distance are one fused
+    kernel (`GamElbo`), with no (C+2)*B*V device-to-host copies unless maps are asked for;
+  * the sparse-GP gains of all continuous covariates are evaluated batched, without host syncs;
+  * parameters live in one flat HBM buffer updated by a fused Adam (optim.FusedAdam).
+
+There is no CPU fallback: `forward` needs the HIP library and a GPU and says so.
+"""
+import datetime
+import os
+
+import numpy as np
+import torch
+import torch.utils.data
+from torch import nn
+from torch.nn import functional as F
+
+from . import gp, ops, utils
+from .optim import FusedAdam
+from .schema import REF_CSV_COLS, REF_IMG_KEYS, covariate_schema, net_geometry, parameter_sets
+
+IMG_SHAPE = (41, 49, 35)
+IMG_DIM = int(np.prod(IMG_SHAPE))
+
+
+class _NullWriter:
+    """Stand-in when tensorboard is absent or logging is off (the reference logs images on every
+    forward, vae_reg_GP.py:333-337; here that is opt-in and never inside the timed path)."""
+    def __getattr__(self, name):
+        return lambda *a, **k: None
+
+
+def _make_writer(log_dir, enabled):
+    if not enabled:
+        return _NullWriter()
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        return SummaryWriter(log_dir=log_dir)
+    except Exception:
+        return _NullWriter()
+
+
+class VAE(nn.Module):
+    def __init__(self, nf=8, save_dir='', lr=1e-3, num_covariates=8, num_latents=32, device_name="auto",
+                 num_inducing_pts=6, gp_kl_scale=10.0, glm_maps='', glm_reg_scale=1.0, csv_files='',
+                 neural_covariates=True, *, img_shape=IMG_SHAPE, xu_ranges=None, tensorboard=False,
+                 data_parallel=None):
+        """Arguments up to `neural_covariates` are the reference's (vae_reg_GP.py:36-37).
+        Keyword-only extensions: `img_shape` (41x49x35 or 82x98x70), `xu_ranges` (inducing-point
+        ranges given directly instead of read from `csv_files`), `tensorboard` (off by default),
+        `data_parallel` (a dp.DataParallelContext).  `glm_maps` may be a CSV path (reference) or an
+        array of shape (V, C+1) whose column 0 is the CSV index column."""
+        super(VAE, self).__init__()
+        self.nf, self.save_dir, self.lr = nf, save_dir, lr
+        self.num_covariates, self.num_latents = num_covariates, num_latents
+        self.neural_covariates = neural_covariates
+        self.z_dim = self.num_latents + self.num_covariates + 1
+        self.img_shape = tuple(int(v) for v in img_shape)
+        self.img_dim = int(np.prod(self.img_shape))
+        self.geom = net_geometry(self.img_shape, nf)
+        self.schema = covariate_schema(num_covariates, neural_covariates)
+        self.dp = data_parallel
+        assert device_name != "cuda" or torch.cuda.is_available()
+        if device_name == "auto":
+            device_name = "cuda" if torch.cuda.is_available() else "cpu"
+        self.device = torch.device(device_name)           # (the reference leaves self.device unset for "cpu"/"cuda", H6)
+        if self.save_dir != '' and not os.path.exists(self.save_dir):
+            os.makedirs(self.save_dir)
+        # log-precision map (vae_reg_GP.py:54-56)
+        self.epsilon = torch.nn.Parameter(-np.log(10) * torch.ones(self.img_shape, dtype=torch.float64))
+        # GLM maps (vae_reg_GP.py:58-59): (V, C+1) float64, column 0 = CSV index
+        if isinstance(glm_maps, str):
+            import pandas as pd
+            glm_np = pd.read_csv(glm_maps).to_numpy()
+        else:
+            glm_np = np.asarray(glm_maps, dtype=np.float64)
+        if glm_np.shape[0] != self.img_dim or glm_np.shape[1] < self.num_covariates + 1:
+            raise ValueError('glm_maps has shape %r, expected (%d, >=%d)' % (glm_np.shape, self.img_dim, self.num_covariates + 1))
+        self.glm_maps = torch.from_numpy(np.ascontiguousarray(glm_np)).to(self.device)
+        self.glm_reg_scale = glm_reg_scale
+        self.inducing_pts = num_inducing_pts
+        self.gp_kl_scale = torch.as_tensor((gp_kl_scale)).to(self.device)
+        self.max_ls = torch.as_tensor(3.0).to(self.device)
+        if xu_ranges is None:
+            xu_ranges = utils.get_xu_ranges(csv_files)
+        # gain parameters, same RNG draw order as vae_reg_GP.py:72-172
+        sets = parameter_sets(num_covariates, neural_covariates)
+        self.gp_params = {c.name: {} for c in sets}
+        k = 0
+        for c in sets:
+            d = self.gp_params[c.name]
+            if c.gp:
+                lo, hi = xu_ranges[k]; k += 1
+                xu = torch.linspace(lo, hi, self.inducing_pts).to(self.device)
+                setattr(self, 'xu_' + c.name, xu); d['xu'] = xu
+                self._gain_param(c.name, 'qu_m', 'qu_m_', torch.normal(0.0, 1.0, size=[1, self.inducing_pts]))
+                self._gain_param(c.name, 'qu_S', 'qu_S_', 2 * torch.eye(self.inducing_pts))
+                self._gain_param(c.name, 'logkvar', 'logkvar_', torch.as_tensor((0.0)))
+                self._gain_param(c.name, 'log_ls', 'logls_', torch.as_tensor((0.0)))
+            self._gain_param(c.name, 'sa', 'sa_', torch.normal(1, 1, size=(1, 1)))
+            self._gain_param(c.name, 'logstd', 'logstd_', torch.normal(0, 1, size=(1, 1)))
+        self._build_network()
+        self.to(self.device)
+        named = list(self.named_parameters())
+        self.optimizer = FusedAdam(named, lr=self.lr)
+        # parameters that take part in training (the reference's Adam only ever creates state for those):
+        # everything except the gain sets of covariates beyond num_covariates
+        used_gain = {c.name for c in self.schema}
+        self.optimizer.used = {i for i, (n, _) in enumerate(named) if self._gain_cov(n) in (None, *used_gain)}
+        self.epoch = 0
+        self.loss = {'train': {}, 'test': {}}
+        ts = datetime.datetime.now().date()
+        self.writer = _make_writer(os.path.join(self.save_dir, 'run', ts.strftime('%m_%d_%Y')), tensorboard)
+        self.log_maps = False          # per-forward image logging of the reference; opt-in
+        self._hrf_cache = {}
+        self._glm_f32 = None
+
+    # ------------------------------------------------------------------ construction helpers
+    _GAIN_PREFIXES = ('sa_', 'logstd_', 'qu_m_', 'qu_S_', 'logkvar_', 'logls_')
+
+    def _gain_cov(self, n):
+        """covariate name of a gain-parameter attribute ('qu_S_xrot' -> 'xrot'), None for other parameters"""
+        for pre in self._GAIN_PREFIXES:
+            if n.startswith(pre):
+                return n[len(pre):]
+        return None
+
+    def _gain_param(self, cov, key, attr_prefix, value):
+        p = torch.nn.Parameter(value.to(self.device))
+        setattr(self, attr_prefix + cov, p)
+        self.gp_params[cov][key] = p
+
+    def _build_network(self):
+        """Same layers, same registration (= RNG and named_parameters) order as vae_reg_GP.py:187-218.
+        The nn modules hold the parameters (state_dict / checkpoint compatibility); the arithmetic is
+        done by ops.bn_conv_act on the HIP kernels."""
+        nf, g = self.nf, self.geom
+        e, d = g.enc, g.dec
+        self.conv1 = nn.Conv3d(1, nf, 3, 1)
+        self.conv2 = nn.Conv3d(nf, nf, 3, 2)
+        self.conv3 = nn.Conv3d(nf, 2 * nf, 3, 1)
+        self.conv4 = nn.Conv3d(2 * nf, 2 * nf, 3, 2)
+        self.conv5 = nn.Conv3d(2 * nf, 2 * nf, 3, 1)
+        self.bn1 = nn.BatchNorm3d(1, track_running_stats=False)
+        self.bn3 = nn.BatchNorm3d(nf, track_running_stats=False)
+        self.bn5 = nn.BatchNorm3d(2 * nf, track_running_stats=False)
+        self.fc1 = nn.Linear(g.enc_flat, 200)
+        self.fc2 = nn.Linear(200, 100)
+        self.fc31 = nn.Linear(100, 50)
+        self.fc32 = nn.Linear(100, 50)
+        self.fc33 = nn.Linear(100, 50)
+        self.fc41 = nn.Linear(50, self.num_latents)
+        self.fc42 = nn.Linear(50, self.num_latents)
+        self.fc43 = nn.Linear(50, self.num_latents)
+        self.fc5 = nn.Linear(self.z_dim, 50)
+        self.fc6 = nn.Linear(50, 100)
+        self.fc7 = nn.Linear(100, 200)
+        self.fc8 = nn.Linear(200, g.dec_flat)
+        self.convt1 = nn.ConvTranspose3d(2 * nf, 2 * nf, d[0].k, d[0].stride)
+        self.convt2 = nn.ConvTranspose3d(2 * nf, 2 * nf, d[1].k, d[1].stride, padding=d[1].pad, output_padding=d[1].outpad)
+        self.convt3 = nn.ConvTranspose3d(2 * nf, nf, d[2].k, d[2].stride)
+        self.convt4 = nn.ConvTranspose3d(nf, nf, d[3].k, d[3].stride)
+        self.convt5 = nn.ConvTranspose3d(nf, 1, d[4].k, d[4].stride)
+        self.bnt1 = nn.BatchNorm3d(2 * nf, track_running_stats=False)
+        self.bnt3 = nn.BatchNorm3d(2 * nf, track_running_stats=False)
+        self.bnt5 = nn.BatchNorm3d(nf, track_running_stats=False)
+
+    def _get_layers(self):
+        """name -> layer, the 28 checkpoint entries of vae_reg_GP.py:220-234."""
+        names = ['fc1', 'fc2', 'fc31', 'fc32', 'fc33', 'fc41', 'fc42', 'fc43', 'fc5', 'fc6', 'fc7', 'fc8', 'bn1', 'bn3',
+                 'bn5', 'bnt1', 'bnt3', 'bnt5', 'conv1', 'conv2', 'conv3', 'conv4', 'conv5', 'convt1', 'convt2', 'convt3',
+                 'convt4', 'convt5']
+        return {n: getattr(self, n) for n in names}
+
+    # ------------------------------------------------------------------ network on the HIP kernels
+    def _require_gpu(self, t):
+        if not t.is_cuda:
+            from . import _lib
+            if not _lib.test_library_injected():
+                raise RuntimeError('vae_gam_amd runs the VAE-GAM step on HIP kernels only: tensors must be on an MI355X '
+                                   '(device "cuda"); there is no CPU path.')
+
+    def _sync(self):
+        return None if self.dp is None else self.dp.bn_sync
+
+    def _encode_pre(self, x):
+        """Encoder conv stack; returns conv5's pre-activation (B, 2nf, d, h, w)."""
+        self._require_gpu(x)
+        e = self.geom.enc
+        B = x.shape[0]
+        h = x.reshape(B, 1, *self.img_shape).contiguous()
+        s = self._sync()
+        p = ops.bn_conv_act(h, self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias, e[0], False, B, True, s)
+        p = ops.bn_conv_act(p, self.conv2.weight, self.conv2.bias, None, None, e[1], True, B, False, s)
+        p = ops.bn_conv_act(p, self.conv3.weight, self.conv3.bias, self.bn3.weight, self.bn3.bias, e[2], True, B, False, s)
+        p = ops.bn_conv_act(p, self.conv4.weight, self.conv4.bias, None, None, e[3], True, B, False, s)
+        p = ops.bn_conv_act(p, self.conv5.weight, self.conv5.bias, self.bn5.weight, self.bn5.bias, e[4], True, B, False, s)
+        return p
+
+    def encode(self, x):
+        """x (B, *img) -> mu (B,L), u (B,L,1), d (B,L)   (vae_reg_GP.py:236-252)."""
+        p = self._encode_pre(x)
+        h = F.relu(p).reshape(p.shape[0], -1)
+        h = F.relu(self.fc1(h))
+        h = F.relu(self.fc2(h))
+        mu = self.fc41(F.relu(self.fc31(h)))
+        u = self.fc42(F.relu(self.fc32(h))).unsqueeze(-1)
+        d = torch.exp(self.fc43(F.relu(self.fc33(h))))
+        return mu, u, d
+
+    def _decode_logits(self, z, per_group):
+        """z (N, z_dim), N = groups*per_group -> pre-sigmoid maps (N, V).  Batch-norm statistics are
+        kept per group of `per_group` consecutive samples (one group per one-hot variant)."""
+        self._require_gpu(z)
+        dsp = self.geom.dec
+        s = self._sync()
+        h = F.relu(self.fc5(z))
+        h = F.relu(self.fc6(h))
+        h = F.relu(self.fc7(h))
+        p = self.fc8(h).view(-1, 2 * self.nf, *self.geom.dec_seed)          # ReLU applied by convt1's loader
+        p = ops.bn_conv_act(p, self.convt1.weight, self.convt1.bias, self.bnt1.weight, self.bnt1.bias, dsp[0], True, per_group, False, s)
+        p = ops.bn_conv_act(p, self.convt2.weight, self.convt2.bias, None, None, dsp[1], True, per_group, False, s)
+        p = ops.bn_conv_act(p, self.convt3.weight, self.convt3.bias, self.bnt3.weight, self.bnt3.bias, dsp[2], True, per_group, False, s)
+        p = ops.bn_conv_act(p, self.convt4.weight, self.convt4.bias, None, None, dsp[3], True, per_group, False, s)
+        p = ops.bn_conv_act(p, self.convt5.weight, self.convt5.bias, self.bnt5.weight, self.bnt5.bias, dsp[4], True, per_group, False, s)
+        return p.reshape(p.shape[0], self.img_dim)
+
+    def decode(self, z):
+        """z (B, z_dim) -> sigmoid maps (B, V)   (vae_reg_GP.py:254-264)."""
+        return torch.sigmoid(self._decode_logits(z, z.shape[0]))
+
+    # ------------------------------------------------------------------ probabilistic pieces
+    def calc_linW_KL(self, sa, std):
+        """KL(N(sa, std^2) || N(1, 0.5^2))   (vae_reg_GP.py:266-281)."""
+        var_ratio = (std / 0.5).pow(2)
+        t1 = ((sa - 1.0) / 0.5).pow(2)
+        return 0.5 * (var_ratio + t1 - 1 - var_ratio.log())
+
+    def _hrf_matrix(self, B, device):
+        key = (B, str(device))
+        if key not in self._hrf_cache:
+            hk = torch.tensor(utils.hrf(np.arange(0, 20, 1.4))).float()          # fp32 on assignment, :299
+            T = torch.zeros(B, B)
+            for i in range(B):
+                n = min(hk.shape[0], B - i)
+                T[i, i:i + n] = hk[:n]
+            self._hrf_cache[key] = T.to(device)
+        return self._hrf_cache[key]
+
+    def do_hrf_conv(self, covariate_vals):
+        """Causal HRF convolution along the batch axis (vae_reg_GP.py:283-305): the reference's
+        (B, B+14) Toeplitz product truncated to B columns, with the matrix cached per batch size."""
+        B = covariate_vals.shape[0]
+        return (covariate_vals.unsqueeze(0) @ self._hrf_matrix(B, covariate_vals.device)).squeeze(0)
+
+    def draw_noise(self, B, device):
+        """The reference's draws per forward, in its order: (B,1), (B,L), then C x (B,)  (SURVEY 4)."""
+        return {'eps_w': torch.randn(B, 1, device=device), 'eps_d': torch.randn(B, self.num_latents, device=device),
+                'eps_beta': torch.randn(self.num_covariates, B, device=device)}
+
+    def _gains(self, covariates, eps_beta):
+        """All C gains of a minibatch at once (vae_reg_GP.py:345-378).
+        covariates (B, C) -> task_var (C, B), gp_kl_loss (1,), and the per-covariate beta mean/cov."""
+        B, C = covariates.shape[0], self.num_covariates
+        dev = covariates.device
+        names = [c.name for c in self.schema]
+        # This block is a few KB of dense algebra per step but numerically the most fragile part of the
+        # model: the BxB gain covariance is close to singular (1e-5 jitter, vae_reg_GP.py:368) and in fp32
+        # the reference's own gradients through its Cholesky are rounding noise at batch 32 (SURVEY H2,
+        # tests/test_model_gpu.py).  It is evaluated in float64 here -- free on MI355X at this size --
+        # and handed to the fp32 kernels as fp32; parameters and their gradients stay fp32.
+        f64 = torch.float64
+        xq = covariates.t().contiguous().to(f64)                                            # (C, B)
+        sa = torch.cat([self.gp_params[n]['sa'][0] for n in names]).to(f64)                 # (C,)
+        std = torch.cat([self.gp_params[n]['logstd'][0] for n in names]).to(f64).exp()
+        gp_kl_loss = self.calc_linW_KL(sa, std).sum().reshape(1)                            # :346-348
+        beta_mean = sa.unsqueeze(1) * xq                                                    # :349
+        eye = torch.eye(B, device=dev, dtype=f64)
+        beta_cov = (std.pow(2).unsqueeze(1) * xq.pow(2)).unsqueeze(-1) * eye                # :350-351 (diagonal)
+        gidx = [i for i, c in enumerate(self.schema) if c.gp]
+        post = None
+        if gidx:
+            gn = [names[i] for i in gidx]
+            xu = torch.stack([self.gp_params[n]['xu'] for n in gn])
+            kvar = torch.stack([self.gp_params[n]['logkvar'] for n in gn]).to(f64).exp() + 0.1     # :355
+            ls = 3.0 * torch.sigmoid(torch.stack([self.gp_params[n]['log_ls'] for n in gn]).to(f64).exp() + 0.5)  # :357
+            qu_m = torch.cat([self.gp_params[n]['qu_m'] for n in gn]).to(f64)
+            qu_S = torch.stack([self.gp_params[n]['qu_S'] for n in gn]).to(f64)
+            f_bar, Sigma = gp.posterior_batched(xu, kvar, ls, qu_m, qu_S, xq[gidx])
+            sel = torch.zeros(C, len(gidx), device=dev, dtype=f64)
+            sel[gidx, list(range(len(gidx)))] = 1.0
+            beta_mean = beta_mean + sel @ f_bar                                             # :363
+            beta_cov = beta_cov + (sel @ Sigma.reshape(len(gidx), -1)).reshape(C, B, B)     # :364
+            gp_kl_loss = gp_kl_loss + gp.kl_batched(qu_m, qu_S).sum()                       # :366-367
+            post = (gn, f_bar, Sigma)
+        L = torch.linalg.cholesky_ex(beta_cov + 1e-5 * eye, check_errors=False).L           # :368
+        task_var = beta_mean + (L @ eps_beta.to(f64).unsqueeze(-1)).squeeze(-1)             # :369
+        hidx = [i for i, c in enumerate(self.schema) if c.hrf]
+        if hidx:                                                                            # :377-378
+            T = self._hrf_matrix(B, dev).to(f64)
+            conv = task_var @ T
+            m = torch.zeros(C, 1, device=dev, dtype=f64); m[hidx] = 1.0
+            task_var = m * conv + (1 - m) * task_var
+        return task_var.float(), gp_kl_loss.float(), beta_mean, beta_cov, post
+
+    def _glm(self):
+        if self._glm_f32 is None or self._glm_f32.device != self.glm_maps.device:
+            C = self.num_covariates
+            self._glm_f32 = self.glm_maps[:, 1:C + 1].t().contiguous().float()              # (C, V)
+        return self._glm_f32
+
+    # ------------------------------------------------------------------ forward
+    def forward_core(self, covariates, x, noise=None, want_maps=False):
+        """The arithmetic of VAE.forward (vae_reg_GP.py:307-410), on device, no host syncs.
+        Returns a dict of device tensors: loss (1,), z, mu, u, d, kl_z, task_var (C,B), gp_kl_loss,
+        glm_reg, sum_log_prob, logits (C+1,B,V) and, if asked, maps (C+2,B,V)."""
+        B, C, L = x.shape[0], self.num_covariates, self.num_latents
+        dev = x.device
+        x = x.float()
+        covariates = covariates.float()
+        if noise is None:
+            noise = self.draw_noise(B, dev)
+        mu, u, d = self.encode(x)
+        d = d + 1e-6 * (d < 1e-6).any().to(d.dtype)                                        # :321-323 without the sync
+        w = u.squeeze(-1)
+        z = mu + w * noise['eps_w'] + d.sqrt() * noise['eps_d']                             # rsample, :325
+        cap = 1.0 + (w * w / d).sum(-1)
+        kl_z = 0.5 * (-(cap.log() + d.log().sum(-1)) + d.sum(-1) + (w * w).sum(-1) + (mu * mu).sum(-1) - L)   # :400
+        G = C + 1
+        oh = torch.eye(G, device=dev).unsqueeze(1).expand(G, B, G)
+        zcat = torch.cat([z.unsqueeze(0).expand(G, B, L), oh], 2).reshape(G * B, L + G)     # :326-329, 339-342
+        logits = self._decode_logits(zcat, B).view(G, B, self.img_dim)
+        task_var, gp_kl_loss, beta_mean, beta_cov, post = self._gains(covariates, noise['eps_beta'])
+        xf = x.reshape(B, self.img_dim)
+        slp, dist = ops.GamElbo.apply(logits, task_var, xf, self.epsilon.view(-1), self._glm())
+        glm_reg = B * dist.sum()                                                            # :388-389
+        elbo = (-kl_z + slp).mean(0)                                                        # :406-408
+        loss = -elbo + self.gp_kl_scale * gp_kl_loss + self.glm_reg_scale * glm_reg         # :410
+        out = dict(loss=loss, z=z, mu=mu, u=u, d=d, kl_z=kl_z, task_var=task_var, gp_kl_loss=gp_kl_loss,
+                   glm_reg=glm_reg, sum_log_prob=slp, dist=dist, logits=logits, beta_mean=beta_mean, beta_cov=beta_cov,
+                   gp_post=post)
+        if want_maps:
+            out['maps'] = ops.gam_maps(logits.detach(), task_var.detach(), xf, self.epsilon.detach().view(-1), self._glm())
+        return out
+
+    def forward(self, ids, covariates, x, log_type, return_latent_rec=False, train_mode=True, noise=None):
+        """Reference signature (vae_reg_GP.py:307).  Returns the loss (shape (1,)), or
+        (loss, z ndarray (B,L), imgs dict of ndarrays (B,V)) with return_latent_rec=True."""
+        want_maps = return_latent_rec or (train_mode and self.log_maps)
+        out = self.forward_core(covariates, x, noise, want_maps)
+        if train_mode and self.log_maps:
+            maps = out['maps']
+            for sl in (12, 15, 18):
+                utils.log_map(self.writer, self.img_shape, maps[0], sl, 'base_map', ids.shape[0], log_type)
+                utils.log_map(self.writer, self.img_shape, maps[1], sl, 'task_map', ids.shape[0], log_type)
+                utils.log_map(self.writer, self.img_shape, maps[-1], sl, 'full_reconstruction', ids.shape[0], log_type)
+        if return_latent_rec:
+            maps = out['maps'].cpu().numpy()
+            imgs = {k: {} for k in REF_IMG_KEYS} if self.num_covariates <= 8 else {}
+            imgs['base'] = maps[0]
+            for i, c in enumerate(self.schema, start=1):
+                imgs[c.img_key] = maps[i]
+            imgs['full_rec'] = maps[-1]
+            return out['loss'], out['z'].detach().cpu().numpy(), imgs
+        return out['loss']
+
+    # ------------------------------------------------------------------ training
+    def _batch_to_device(self, sample):
+        x = sample['volume'].to(self.device, non_blocking=True)
+        covariates = sample['covariates'].to(self.device, non_blocking=True)
+        ids = sample['subjid'].to(self.device, non_blocking=True)
+        return ids, covariates, x
+
+    def train_step(self, ids, covariates, x, noise=None):
+        """One iteration of train_epoch's body (vae_reg_GP.py:425-429); returns the loss tensor (1,)."""
+        loss = self.forward(ids, covariates, x, 'train', train_mode=True, noise=noise)
+        self.optimizer.zero_grad()
+        loss.backward()
+        if self.dp is not None:
+            self.dp.allreduce_grads(self.optimizer.flat_grads())
+        self.optimizer.step()
+        return loss.detach()
+
+    def train_epoch(self, train_loader):
+        self.train()
+        total = torch.zeros((), dtype=torch.float64, device=self.device)
+        for batch_idx, sample in enumerate(train_loader):
+            ids, covariates, x = self._batch_to_device(sample)
+            total += self.train_step(ids, covariates, x).sum().double()
+        train_loss = float(total.item()) / len(train_loader.dataset)     # one sync per epoch (the reference syncs per batch, :426)
+        print('Epoch: {} Average loss: {:.4f}'.format(self.epoch, train_loss))
+        self.epoch += 1
+        return train_loss
+
+    def test_epoch(self, test_loader):
+        self.eval()
+        total = torch.zeros((), dtype=torch.float64, device=self.device)
+        with torch.no_grad():
+            for i, sample in enumerate(test_loader):
+                ids, covariates, x = self._batch_to_device(sample)
+                total += self.forward(ids, covariates, x, 'test', train_mode=False).sum().double()
+        test_loss = float(total.item()) / len(test_loader.dataset)
+        print('Test loss: {:.4f}'.format(test_loss))
+        return test_loss
+
+    def train_loop(self, loaders, epochs=100, test_freq=2, save_freq=10, save_dir=''):
+        """vae_reg_GP.py:691-715 (same prints, cadence and checkpoint names)."""
+        print("=" * 40)
+        print("Training: epochs", self.epoch, "to", self.epoch + epochs - 1)
+        print("Training set:", len(loaders['Shuffled_train'].dataset))
+        print("Test set:", len(loaders['test'].dataset))
+        print("=" * 40)
+        for epoch in range(self.epoch, self.epoch + epochs):
+            loss = self.train_epoch(loaders['Shuffled_train'])
+            self.loss['train'][epoch] = loss
+            self.writer.add_scalar("Loss/Train", loss, self.epoch)
+            self.writer.flush()
+            if (test_freq is not None) and (epoch % test_freq == 0):
+                loss = self.test_epoch(loaders['test'])
+                self.loss['test'][epoch] = loss
+            if (save_freq is not None) and (epoch % save_freq == 0) and (epoch > 0):
+                filename = "checkpoint_" + str(epoch).zfill(3) + '.tar'
+                file_path = os.path.join(save_dir, filename)
+                self.save_state(file_path)
+        self.writer.close()
+
+    # ------------------------------------------------------------------ checkpoints
+    def save_state(self, filename):
+        """Same dictionary as vae_reg_GP.py:452-471."""
+        layers = self._get_layers()
+        state = {}
+        for layer_name in layers:
+            state[layer_name] = {k: v.detach().clone() for k, v in layers[layer_name].state_dict().items()}
+        state['optimizer_state'] = self.optimizer.state_dict()
+        state['loss'] = self.loss
+        state['z_dim'] = self.z_dim
+        state['epoch'] = self.epoch
+        state['lr'] = self.lr
+        state['save_dir'] = self.save_dir
+        state['epsilon'] = torch.nn.Parameter(self.epsilon.detach().clone())
+        state['glm_reg_scale'] = self.glm_reg_scale
+        state['gp_kl_scale'] = self.gp_kl_scale
+        state['inducing_pts'] = self.inducing_pts
+        gp_out = {}
+        for cov, d in self.gp_params.items():
+            gp_out[cov] = {k: (torch.nn.Parameter(v.detach().clone()) if isinstance(v, torch.nn.Parameter) else v.clone())
+                           for k, v in d.items()}
+        state['gp_params'] = gp_out
+        filename = os.path.join(self.save_dir, filename)
+        torch.save(state, filename)
+
+    def load_state(self, filename):
+        """vae_reg_GP.py:473-539.  Values are copied INTO the live parameters, so the optimiser keeps
+        updating epsilon and the gain parameters after a resume (the reference rebinds fresh tensors
+        the optimiser never sees)."""
+        checkpoint = torch.load(filename, map_location=self.device, weights_only=False)
+        assert checkpoint['z_dim'] == self.z_dim
+        layers = self._get_layers()
+        with torch.no_grad():
+            for layer_name in layers:
+                for k, v in checkpoint[layer_name].items():
+                    layers[layer_name].state_dict()[k].copy_(v)
+            self.epsilon.copy_(checkpoint['epsilon'].detach().to(self.device))
+            for cov, d in checkpoint['gp_params'].items():
+                for key, v in d.items():
+                    tgt = self.gp_params[cov][key]
+                    tgt.data.copy_(v.detach().to(self.device)) if isinstance(tgt, torch.nn.Parameter) else tgt.copy_(v.to(self.device))
+        self.optimizer.load_state_dict(checkpoint['optimizer_state'])
+        self.loss = checkpoint['loss']
+        self.epoch = checkpoint['epoch']
+        self.glm_reg_scale = checkpoint['glm_reg_scale']
+        self.gp_kl_scale = torch.as_tensor(checkpoint['gp_kl_scale']).to(self.device)
+        self.inducing_pts = checkpoint['inducing_pts']
+
+    # ------------------------------------------------------------------ post-hoc (reconstruction export lives in build_model_recons)
+    def reconstruct_batch(self, ids, covariates, x):
+        """Maps of one batch as ndarrays keyed like the reference's `imgs` (vae_reg_GP.py:605)."""
+        with torch.no_grad():
+            _, _, imgs = self.forward(ids, covariates, x, 'reconstruction', return_latent_rec=True, train_mode=False)
+        return imgs
+
+
+if __name__ == "__main__":
+    pass
