@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- fMRI volumes/sec through the full VAE-GAM train step on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run with one rank per GPU.  Prints ONE JSON line on rank 0.
+
+Workload (`config.workload`): BASELINE.json configs[1] -- synthetic checker-control set
+(2 subjects x 98 volumes of 41x49x35, 'Large3' control signal), 3 covariates [task, x, y],
+batch 32 PER GPU (weak scaling), random-init weights (seed 1), fp32, data resident in HBM.
+A step = forward + backward + (N>1: RCCL all-reduce of the flat gradient buffer) + fused Adam on
+one minibatch.  `value` = N * 32 * K / t, t = max over ranks of the barrier-bracketed wall time.
+
+roofline: the dominant kernel's ALGORITHMIC bytes (what it must read + write once, DESIGN.md
+"Kernels") / its mean duration, measured with HIP events recorded on the launching stream inside
+this run, against 8 TB/s.  cpu_baseline: the CPU oracle (oracle/vaegam_oracle.py, a "port" of the
+reference checked against reference goldens) timed on the host cores of this box on a bounded
+sample of the same workload, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+FP32_PEAK_TF = 157.3
+ALG_BYTES_PER_VOL = {3: 69.6e6, 8: 139.2e6, 12: 194.8e6}
+ALG_GFLOP_PER_VOL = {3: 1.600, 8: 3.241, 12: 4.555}
+
+
+def host_threads():
+    """CPU threads this process may really use (cgroup quota / affinity), capped at the box's share."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def alg_bytes_per_launch(key, model, B):
+    """Algorithmic HBM bytes of ONE launch of a kernel: every element it must read or write, once.
+    key = '<entry point>:<layer>/<fwd|bwd>' as tagged by vae_gam_amd.ops."""
+    import numpy as np
+    fn, tag = key.split(':')
+    if '/' not in tag:
+        return None
+    lname, direction = tag.split('/')
+    geom = model.geom
+    G = model.num_covariates + 1
+    if lname.startswith('convt'):
+        i = int(lname[5:]) - 1; sp = geom.dec[i]; sizes = geom.dec_sizes(); N = G * B
+    elif lname.startswith('conv'):
+        i = int(lname[4:]) - 1; sp = geom.enc[i]; sizes = geom.enc_sizes(); N = B
+    else:
+        return None
+    n_in = N * sp.ci * int(np.prod(sizes[i])); n_out = N * sp.co * int(np.prod(sizes[i + 1]))
+    if fn in ('vg_corr3d', 'vg_tconv3d_s2'):
+        extra = n_in if (direction == 'bwd') else 0          # bwd: + the saved activation read for the fused ReLU mask
+        return 4 * (n_in + n_out + extra)
+    if fn == 'vg_wgrad3d':
+        return 4 * (n_in + n_out)
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='minibatch per GPU')
+    ap.add_argument('--covariates', type=int, default=3)
+    ap.add_argument('--subjects', type=int, default=2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel HIP-event table to stderr')
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import vae_gam_amd  # noqa: F401
+    from vae_gam_amd import ops, synthetic, _lib
+    from vae_gam_amd.DataClass_GP import DeviceResidentData
+    from vae_gam_amd.vae_reg_GP import VAE
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: no GPU visible (the hot path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    _lib.get_lib()
+    dp = None
+    if world > 1:
+        from vae_gam_amd import dp as dpmod
+        dp = dpmod.DataParallelContext.from_env()
+
+    B, C = a.batch, a.covariates
+    ds = synthetic.make_dataset(num_subjects=a.subjects, vols_per_subject=98, num_covariates=C, seed=0)
+    torch.manual_seed(1)                                             # CLI default seed (multsubj_reg_run_GP.py:31)
+    model = VAE(num_covariates=C, glm_maps=ds['glm'], xu_ranges=ds['xu_ranges'], device_name='cuda', data_parallel=dp)
+    data = DeviceResidentData(torch.from_numpy(ds['volumes']), torch.from_numpy(ds['covariates']),
+                              torch.from_numpy(ds['subjid']), batch_size=B * world, shuffle=True, seed=0, device=dev,
+                              rank=rank, world=world)
+    batches = list(iter(data))                                       # index tensors resolved once; volumes stay in HBM
+    torch.manual_seed(1234 + 0)                                      # identical device noise stream on every rank
+
+    def run_steps(n, first=0):
+        for s in range(first, first + n):
+            smp = batches[s % len(batches)]
+            model.train_step(smp['subjid'], smp['covariates'], smp['volume'])
+
+    def barrier():
+        if dp is not None:
+            dp.barrier()
+
+    run_steps(a.warmup)
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    ops.PROFILE = {}                                                 # HIP events on the launch stream, timed region
+    t0 = time.perf_counter()
+    run_steps(a.steps, a.warmup)
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if dp is not None:
+        dt = dp.max_scalar(dt)
+    ms_per_step = 1e3 * dt / a.steps
+    value = world * B * a.steps / dt
+
+    # ---- per-kernel table from the events of the timed region
+    rows = []
+    for key, evs in prof.items():
+        tot = sum(e0.elapsed_time(e1) for e0, e1 in evs)             # ms
+        rows.append((tot, key, len(evs)))
+    rows.sort(reverse=True)
+    roofline = None
+    for tot, key, n in rows:
+        ab = alg_bytes_per_launch(key, model, B)
+        if ab is None:
+            continue
+        per = tot / n                                                # ms per launch
+        ach = ab / (per * 1e-3) / 1e9
+        roofline = {'bound': 'hbm', 'kernel': key, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None, 'alg_bytes_per_launch': ab,
+                    'avg_launch_us': round(per * 1e3, 2), 'launches': n,
+                    'share_of_kernel_time': round(tot / max(sum(r[0] for r in rows), 1e-9), 3)}
+        break
+    if a.kernel_table and rank == 0:
+        tsum = sum(r[0] for r in rows)
+        print('%-40s %8s %10s %7s' % ('kernel:layer', 'calls', 'ms/step', 'share'), file=sys.stderr)
+        for tot, key, n in rows:
+            print('%-40s %8d %10.4f %6.1f%%' % (key, n, tot / a.steps, 100 * tot / tsum), file=sys.stderr)
+        print('sum of HIP kernel time %.3f ms/step, wall %.3f ms/step' % (tsum / a.steps, ms_per_step), file=sys.stderr)
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        import bridge
+        import vaegam_oracle as O
+        nthr = host_threads()
+        torch.set_num_threads(nthr)
+        cfg = bridge.oracle_config(model, glm_cdist=True)            # torch.cdist as the reference (vae_reg_GP.py:388)
+        params = bridge.params_from_model(model)
+        opt = O.AdamState(lr=cfg.lr)
+        glm = torch.from_numpy(ds['glm'])
+        smp = batches[0]
+        xc, cc = smp['volume'].cpu(), smp['covariates'].cpu()
+        gen = torch.Generator().manual_seed(0)
+        O.train_step(params, opt, cfg, xc, cc, glm, O.draw_noise(B, cfg, gen))           # warm-up
+        ts = []
+        for _ in range(a.cpu_steps):
+            t1 = time.perf_counter()
+            O.train_step(params, opt, cfg, xc, cc, glm, O.draw_noise(B, cfg, gen))
+            ts.append(time.perf_counter() - t1)
+        med = sorted(ts)[len(ts) // 2]
+        cpu = {'value': round(B / med, 2), 'unit': 'volumes/s', 'cores': nthr, 'kind': 'port',
+               'sample': '%d train steps of batch %d (same synthetic minibatch, logging off), median; PyTorch CPU fp32'
+                         % (a.cpu_steps, B)}
+
+    if rank == 0:
+        out = {
+            'metric': 'fMRI volumes/sec/train-step (41x49x35)', 'value': round(value, 1), 'unit': 'volumes/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: synthetic checker control (Large3), %d subjects x 98 volumes '
+                                   '41x49x35, %d covariates, batch %d per GPU, full train step (fwd+bwd+Adam), '
+                                   'gain/GP algebra on device in fp64' % (a.subjects, C, B),
+                       'global_batch': B * world, 'covariates': C, 'parallelism': 'dp%d' % world},
+            'roofline': roofline,
+            'step_roofline': {'hbm_frac': round(value / world * ALG_BYTES_PER_VOL.get(C, 0) / (HBM_PEAK_GBS * 1e9), 4),
+                              'fp32_frac': round(value / world * ALG_GFLOP_PER_VOL.get(C, 0) / (FP32_PEAK_TF * 1e3), 4),
+                              'alg_bytes_per_volume': ALG_BYTES_PER_VOL.get(C), 'gflop_per_volume': ALG_GFLOP_PER_VOL.get(C)},
+            'cpu_baseline': cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dp is not None:
+        dp.shutdown()
+
+
+if __name__ == '__main__':
+    main()

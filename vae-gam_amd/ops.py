@@ -21,6 +21,36 @@ from ._lib import ConvDesc, WgradDesc
 
 BN_EPS = 1e-5            # nn.BatchNorm3d default (vae_reg_GP.py:194-196)
 
+# Optional per-launch timing with HIP events recorded on the stream the kernels are launched on
+# (bench.py's roofline leg).  PROFILE maps "<entry point>:<layer>" -> list of (start, end) events.
+PROFILE = None
+_LABEL = ['']
+
+
+class label:
+    """with ops.label('convt5'): ... tags the launches inside (profiling only)."""
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = _LABEL[0]; _LABEL[0] = self.name
+
+    def __exit__(self, *a):
+        _LABEL[0] = self.prev
+
+
+def _call(t, fn, *args):
+    """Launch one C-ABI entry point on t's current stream (optionally bracketed by HIP events)."""
+    lib = _lib.get_lib()
+    if PROFILE is not None and t.is_cuda:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        lib.call(fn, *args, _stream(t))
+        e1.record()
+        PROFILE.setdefault('%s:%s' % (fn, _LABEL[0]), []).append((e0, e1))
+    else:
+        lib.call(fn, *args, _stream(t))
+
 
 def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
@@ -49,6 +79,7 @@ class ConvSpec:
     stride: int
     pad: Tuple[int, int, int] = (0, 0, 0)
     outpad: Tuple[int, int, int] = (0, 0, 0)
+    name: str = ''
 
     def out_size(self, i):
         if self.kind == 'conv':
@@ -86,14 +117,14 @@ def conv_forward(x, wpk, bias, spec: ConvSpec, relu_in=False, scale=None, shift=
     if spec.kind == 'conv':
         assert spec.pad == (0, 0, 0)
         d = _conv_desc(N, spec.ci, spec.co, isz, osz, spec.k, spec.stride, (0, 0, 0), relu_in, per_group)
-        lib.call('vg_corr3d', ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(scale), _p(shift), None, _p(y), _stream(x))
+        _call(x, 'vg_corr3d', ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(scale), _p(shift), None, _p(y))
     elif spec.stride == 1:
         padc = tuple(spec.k[a] - 1 - spec.pad[a] for a in range(3))
         d = _conv_desc(N, spec.ci, spec.co, isz, osz, spec.k, 1, padc, relu_in, per_group)
-        lib.call('vg_corr3d', ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(scale), _p(shift), None, _p(y), _stream(x))
+        _call(x, 'vg_corr3d', ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(scale), _p(shift), None, _p(y))
     else:
         d = _conv_desc(N, spec.ci, spec.co, isz, osz, spec.k, 2, spec.pad, relu_in, per_group)
-        lib.call('vg_tconv3d_s2', ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(scale), _p(shift), None, _p(y), _stream(x))
+        _call(x, 'vg_tconv3d_s2', ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(scale), _p(shift), None, _p(y))
     return y
 
 
@@ -107,14 +138,14 @@ def conv_backward_data(dy, wpk_bwd, spec: ConvSpec, in_size, mask_src=None):
     if spec.kind == 'convt':
         # dx[i] = sum_k dy[i*s - pad + k] w[k]: strided correlation over dy
         d = _conv_desc(N, spec.co, spec.ci, osz, isz, spec.k, spec.stride, spec.pad, False, 1)
-        lib.call('vg_corr3d', ctypes.byref(d), _p(dy), _p(wpk_bwd), None, None, None, _p(mask_src), _p(dx), _stream(dy))
+        _call(dy, 'vg_corr3d', ctypes.byref(d), _p(dy), _p(wpk_bwd), None, None, None, _p(mask_src), _p(dx))
     elif spec.stride == 1:
         padc = tuple(spec.k[a] - 1 for a in range(3))
         d = _conv_desc(N, spec.co, spec.ci, osz, isz, spec.k, 1, padc, False, 1)
-        lib.call('vg_corr3d', ctypes.byref(d), _p(dy), _p(wpk_bwd), None, None, None, _p(mask_src), _p(dx), _stream(dy))
+        _call(dy, 'vg_corr3d', ctypes.byref(d), _p(dy), _p(wpk_bwd), None, None, None, _p(mask_src), _p(dx))
     else:
         d = _conv_desc(N, spec.co, spec.ci, osz, isz, spec.k, 2, (0, 0, 0), False, 1)
-        lib.call('vg_tconv3d_s2', ctypes.byref(d), _p(dy), _p(wpk_bwd), None, None, None, _p(mask_src), _p(dx), _stream(dy))
+        _call(dy, 'vg_tconv3d_s2', ctypes.byref(d), _p(dy), _p(wpk_bwd), None, None, None, _p(mask_src), _p(dx))
     return dx
 
 
@@ -135,7 +166,7 @@ def conv_weight_grad(x, dy, spec: ConvSpec, relu_in=False, scale=None, shift=Non
     nbytes = lib.size('vg_wgrad3d_ws_bytes', ctypes.byref(d))
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
     dw = torch.empty(shape, dtype=torch.float32, device=x.device)
-    lib.call('vg_wgrad3d', ctypes.byref(d), _p(a), _p(b), _p(scale), _p(shift), _p(ws), _p(dw), _stream(x))
+    _call(x, 'vg_wgrad3d', ctypes.byref(d), _p(a), _p(b), _p(scale), _p(shift), _p(ws), _p(dw))
     return dw
 
 
@@ -155,15 +186,15 @@ def bn_stats(x, gamma, beta, relu, per_group, sync=None):
     ws = _bn_ws(x, N, C, P, per_group)
     out = torch.empty((4, G * C), dtype=torch.float32, device=x.device)
     if sync is None:
-        lib.call('vg_bn_stats', _p(_chk(x)), N, C, P, per_group, int(relu), _p(gamma), _p(beta), BN_EPS, _p(ws), None,
-                 _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]), _stream(x))
+        _call(x, 'vg_bn_stats', _p(_chk(x)), N, C, P, per_group, int(relu), _p(gamma), _p(beta), BN_EPS, _p(ws), None,
+                 _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]))
     else:
         sums = torch.empty((G * C, 3), dtype=torch.float64, device=x.device)
-        lib.call('vg_bn_stats', _p(_chk(x)), N, C, P, per_group, int(relu), _p(gamma), _p(beta), BN_EPS, _p(ws), _p(sums),
-                 None, None, None, None, _stream(x))
+        _call(x, 'vg_bn_stats', _p(_chk(x)), N, C, P, per_group, int(relu), _p(gamma), _p(beta), BN_EPS, _p(ws), _p(sums),
+                 None, None, None, None)
         sums = sync(sums)
-        lib.call('vg_bn_finalize', _p(sums), G, C, _p(gamma), _p(beta), BN_EPS, _p(out[0]), _p(out[1]), _p(out[2]),
-                 _p(out[3]), _stream(x))
+        _call(x, 'vg_bn_finalize', _p(sums), G, C, _p(gamma), _p(beta), BN_EPS, _p(out[0]), _p(out[1]), _p(out[2]),
+                 _p(out[3]))
     return out[0], out[1], out[2], out[3]
 
 
@@ -176,15 +207,15 @@ def bn_backward_(dxe, p, gamma, mean, rstd, relu, per_group, sync=None):
     G = N // per_group
     ws = _bn_ws(p, N, C, P, per_group)
     sums = torch.empty((G * C, 2), dtype=torch.float64, device=p.device)
-    lib.call('vg_bn_bwd_reduce', _p(_chk(dxe)), _p(_chk(p)), N, C, P, per_group, int(relu), _p(mean), _p(rstd), _p(ws),
-             _p(sums), _stream(p))
+    _call(p, 'vg_bn_bwd_reduce', _p(_chk(dxe)), _p(_chk(p)), N, C, P, per_group, int(relu), _p(mean), _p(rstd), _p(ws),
+             _p(sums))
     count = float(per_group * P)
     if sync is not None:
         sums = sync(sums)
         count = count * sync.world_size
     parts = torch.empty((2, G, C), dtype=torch.float32, device=p.device)
-    lib.call('vg_bn_bwd_apply', _p(dxe), _p(p), N, C, P, per_group, int(relu), _p(gamma), _p(mean), _p(rstd), _p(sums),
-             count, _p(parts[0]), _p(parts[1]), _stream(p))
+    _call(p, 'vg_bn_bwd_apply', _p(dxe), _p(p), N, C, P, per_group, int(relu), _p(gamma), _p(mean), _p(rstd), _p(sums),
+             count, _p(parts[0]), _p(parts[1]))
     return parts[0].sum(0), parts[1].sum(0)
 
 
@@ -194,7 +225,7 @@ def channel_sum(x):
     P = x[0, 0].numel()
     ws = _bn_ws(x, N, C, P, N)
     out = torch.empty(C, dtype=torch.float32, device=x.device)
-    lib.call('vg_channel_sum', _p(_chk(x)), N, C, P, _p(ws), _p(out), _stream(x))
+    _call(x, 'vg_channel_sum', _p(_chk(x)), N, C, P, _p(ws), _p(out))
     return out
 
 
@@ -214,9 +245,10 @@ class BnConvAct(torch.autograd.Function):
         p_in = p_in.contiguous()
         has_bn = gamma is not None
         scale = shift = mean = rstd = None
-        if has_bn:
-            scale, shift, mean, rstd = bn_stats(p_in, gamma, beta, relu_in, per_group, sync)
-        y = conv_forward(p_in, pack_weight(weight, spec, 'fwd'), bias, spec, relu_in, scale, shift, per_group)
+        with label(spec.name + '/fwd'):
+            if has_bn:
+                scale, shift, mean, rstd = bn_stats(p_in, gamma, beta, relu_in, per_group, sync)
+            y = conv_forward(p_in, pack_weight(weight, spec, 'fwd'), bias, spec, relu_in, scale, shift, per_group)
         ctx.spec, ctx.relu_in, ctx.per_group, ctx.input_is_data, ctx.sync, ctx.has_bn = \
             spec, relu_in, per_group, input_is_data, sync, has_bn
         ctx.save_for_backward(p_in, weight, gamma, beta, scale, shift, mean, rstd)
@@ -224,6 +256,11 @@ class BnConvAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        with label(ctx.spec.name + '/bwd'):
+            return BnConvAct._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         p_in, weight, gamma, beta, scale, shift, mean, rstd = ctx.saved_tensors
         spec, relu_in, per_group = ctx.spec, ctx.relu_in, ctx.per_group
         dy = dy.contiguous()
@@ -274,8 +311,8 @@ class GamElbo(torch.autograd.Function):
         ws = torch.empty(lib.size('vg_gam_ws_bytes', C, B, V) // 4 + 1, dtype=torch.float32, device=x.device)
         slp = torch.empty(B, dtype=torch.float32, device=x.device)
         dist = torch.empty((C, B), dtype=torch.float32, device=x.device)
-        lib.call('vg_gam_elbo_fwd', _p(logits), _p(gain), _p(x), _p(eps), _p(glm), C, B, V, _p(ws), _p(slp), _p(dist),
-                 None, _stream(x))
+        _call(x, 'vg_gam_elbo_fwd', _p(logits), _p(gain), _p(x), _p(eps), _p(glm), C, B, V, _p(ws), _p(slp), _p(dist),
+                 None)
         ctx.save_for_backward(logits, gain, x, eps, glm, dist)
         return slp, dist
 
@@ -290,8 +327,8 @@ class GamElbo(torch.autograd.Function):
         d_logits = torch.empty_like(logits)
         d_gain = torch.empty_like(gain)
         d_eps = torch.empty_like(eps)
-        lib.call('vg_gam_elbo_bwd', _p(logits), _p(gain), _p(x), _p(eps), _p(glm), _p(dist), _p(g_slp), _p(g_dist),
-                 C, B, V, _p(ws), _p(d_logits), _p(d_gain), _p(d_eps), _stream(x))
+        _call(x, 'vg_gam_elbo_bwd', _p(logits), _p(gain), _p(x), _p(eps), _p(glm), _p(dist), _p(g_slp), _p(g_dist),
+                 C, B, V, _p(ws), _p(d_logits), _p(d_gain), _p(d_eps))
         return d_logits, d_gain, None, d_eps, None
 
 
@@ -304,9 +341,9 @@ def gam_maps(logits, gain, x, eps, glm):
     slp = torch.empty(B, dtype=torch.float32, device=x.device)
     dist = torch.empty((max(C, 1), B), dtype=torch.float32, device=x.device)
     maps = torch.empty((G + 1, B, V), dtype=torch.float32, device=x.device)
-    lib.call('vg_gam_elbo_fwd', _p(_chk(logits.contiguous())), _p(_chk(gain.contiguous())), _p(_chk(x.contiguous())),
+    _call(x, 'vg_gam_elbo_fwd', _p(_chk(logits.contiguous())), _p(_chk(gain.contiguous())), _p(_chk(x.contiguous())),
              _p(_chk(eps.contiguous(), torch.float64)), _p(_chk(glm.contiguous())), C, B, V, _p(ws), _p(slp), _p(dist),
-             _p(maps), _stream(x))
+             _p(maps))
     return maps
 
 
@@ -315,5 +352,5 @@ def adam_step_(p, g, m, v, b1, b2, eps, step_scalars):
     lib = _lib.get_lib()
     assert p.dtype == g.dtype == m.dtype == v.dtype and p.dtype in (torch.float32, torch.float64)
     assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
-    lib.call('vg_adam_step', _p(p), _p(g), _p(m), _p(v), p.numel(), int(p.dtype == torch.float64), float(b1), float(b2),
-             float(eps), _p(_chk(step_scalars, torch.float64)), _stream(p))
+    _call(p, 'vg_adam_step', _p(p), _p(g), _p(m), _p(v), p.numel(), int(p.dtype == torch.float64), float(b1), float(b2),
+             float(eps), _p(_chk(step_scalars, torch.float64)))

@@ -100,6 +100,9 @@ def net_geometry(img: Sequence[int], nf: int = 8) -> NetGeometry:
         seed = (16, 20, 13)
     else:
         raise ValueError('no network geometry defined for image shape %r' % (img,))
+    from dataclasses import replace
+    enc = tuple(replace(sp, name='conv%d' % (i + 1)) for i, sp in enumerate(enc))
+    dec = tuple(replace(sp, name='convt%d' % (i + 1)) for i, sp in enumerate(dec))
     g = NetGeometry(img, nf, enc, dec, seed)
     assert g.dec_sizes()[-1] == img, (g.dec_sizes(), img)
     return g
