@@ -78,6 +78,7 @@ def main():
     ap.add_argument('--subjects', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--eager', action='store_true', help='launch kernels eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel HIP-event table to stderr')
     a = ap.parse_args()
 
@@ -122,14 +123,25 @@ def main():
         if dp is not None:
             dp.barrier()
 
+    model.use_hip_graph = not a.eager
     run_steps(a.warmup)
+    graphed = bool(model._graphs) and all(v is not False for v in model._graphs.values())
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-    ops.PROFILE = {}                                                 # HIP events on the launch stream, timed region
+    if not graphed:
+        ops.PROFILE = {}                                             # HIP events on the launch stream, timed region
     t0 = time.perf_counter()
     run_steps(a.steps, a.warmup)
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if graphed:
+        # events cannot be recorded inside a replayed graph: time the same launches, same stream, eagerly,
+        # right after the timed region (the kernels and their arguments are identical)
+        model.use_hip_graph = False
+        ops.PROFILE = {}
+        run_steps(max(3, min(a.steps, 10)), a.warmup + a.steps)
+        torch.cuda.synchronize()
     prof, ops.PROFILE = ops.PROFILE, None
+    prof_steps = a.steps if not graphed else max(3, min(a.steps, 10))
     if dp is not None:
         dt = dp.max_scalar(dt)
     ms_per_step = 1e3 * dt / a.steps
@@ -157,8 +169,8 @@ def main():
         tsum = sum(r[0] for r in rows)
         print('%-40s %8s %10s %7s' % ('kernel:layer', 'calls', 'ms/step', 'share'), file=sys.stderr)
         for tot, key, n in rows:
-            print('%-40s %8d %10.4f %6.1f%%' % (key, n, tot / a.steps, 100 * tot / tsum), file=sys.stderr)
-        print('sum of HIP kernel time %.3f ms/step, wall %.3f ms/step' % (tsum / a.steps, ms_per_step), file=sys.stderr)
+            print('%-40s %8d %10.4f %6.1f%%' % (key, n, tot / prof_steps, 100 * tot / tsum), file=sys.stderr)
+        print('sum of HIP kernel time %.3f ms/step (events), wall %.3f ms/step (%s)' % (tsum / prof_steps, ms_per_step, 'hipGraph replay' if graphed else 'eager'), file=sys.stderr)
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -192,7 +204,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: synthetic checker control (Large3), %d subjects x 98 volumes '
                                    '41x49x35, %d covariates, batch %d per GPU, full train step (fwd+bwd+Adam), '
-                                   'gain/GP algebra on device in fp64' % (a.subjects, C, B),
+                                   'gain/GP algebra on device in fp64, %s' % (a.subjects, C, B, 'hipGraph replay' if graphed else 'eager launches'),
                        'global_batch': B * world, 'covariates': C, 'parallelism': 'dp%d' % world},
             'roofline': roofline,
             'step_roofline': {'hbm_frac': round(value / world * ALG_BYTES_PER_VOL.get(C, 0) / (HBM_PEAK_GBS * 1e9), 4),

@@ -63,7 +63,7 @@ def test_adam(dtype):
 
 
 def test_library_refuses_bad_shapes():
-    spec = ops.ConvSpec('conv', 8, 4, (3, 3, 3), 1)                  # CO=4 has no kernel instance
-    x = torch.zeros(1, 8, 5, 5, 5, device='cuda'); w = torch.zeros(4, 8, 3, 3, 3, device='cuda')
+    spec = ops.ConvSpec('conv', 8, 3, (3, 3, 3), 1)                  # CO=3 has no kernel instance
+    x = torch.zeros(1, 8, 5, 5, 5, device='cuda'); w = torch.zeros(3, 8, 3, 3, 3, device='cuda')
     with pytest.raises(_lib.VgError):
         ops.conv_forward(x, ops.pack_weight(w, spec, 'fwd'), None, spec)

@@ -1,0 +1,44 @@
+"""Which part of the train step refuses hipGraph stream capture?  (diagnostic, run on the GPU box)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import vae_gam_amd
+from vae_gam_amd import synthetic
+from vae_gam_amd.vae_reg_GP import VAE
+
+ds = synthetic.make_dataset(num_subjects=1, vols_per_subject=40, num_covariates=3, seed=0)
+torch.manual_seed(1)
+m = VAE(num_covariates=3, glm_maps=ds['glm'], xu_ranges=ds['xu_ranges'], device_name='cuda')
+B = 32
+x = torch.from_numpy(ds['volumes'][:B]).cuda(); cov = torch.from_numpy(ds['covariates'][:B]).cuda()
+ids = torch.zeros(B, dtype=torch.int64, device='cuda')
+
+
+def probe(name, fn):
+    try:
+        s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fn(); fn()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        g.replay(); torch.cuda.synchronize()
+        print('CAPTURE OK  ', name, flush=True)
+    except Exception as e:
+        print('CAPTURE FAIL', name, type(e).__name__, str(e).split('\n')[0], flush=True)
+        torch.cuda.synchronize()
+
+
+noise = m.draw_noise(B, x.device)
+probe('randn', lambda: m.draw_noise(B, x.device))
+probe('inv_ex f64', lambda: torch.linalg.inv_ex(torch.eye(6, device='cuda', dtype=torch.float64).expand(2, 6, 6) * 2, check_errors=False))
+probe('cholesky_ex f64', lambda: torch.linalg.cholesky_ex(torch.eye(32, device='cuda', dtype=torch.float64).expand(3, 32, 32) * 2, check_errors=False))
+probe('gains', lambda: m._gains(cov, noise['eps_beta']))
+probe('encode', lambda: m.encode(x))
+probe('forward_core', lambda: m.forward_core(cov, x, noise))
+def fb():
+    m.optimizer.zero_grad(); l = m.forward(ids, cov, x, 'train', noise=noise); l.backward()
+probe('fwd+bwd', fb)
+probe('adam', lambda: m.optimizer.apply_update())

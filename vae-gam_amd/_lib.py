@@ -77,7 +77,7 @@ _INJECTED = False
 
 
 def library_path():
-    return os.path.join(_HERE, LIB_NAME)
+    return os.path.join(_HERE, LIB_NAME)          # the one product library; nothing else is ever searched
 
 
 def get_lib() -> VgLibrary:

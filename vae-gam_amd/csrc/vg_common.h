@@ -15,11 +15,20 @@
 #define VG_DYN_SMEM(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 template <typename K, typename... A>
 static inline void vg_launch(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t s, A... args) {
+    (void)hipGetLastError();        // drop any stale error another library left on this thread; vg_check_launch reads ours
     hipLaunchKernelGGL(kernel, grid, block, shmem, s, args...);
 }
 #endif
 
 #define VG_WAVE 64
+
+// wave index inside the block as a wave-uniform (scalar) value: row/tile decoding that depends only
+// on it then runs on the scalar ALU
+#ifdef VG_EMU
+static inline int vg_wave_id() { return threadIdx.x / VG_WAVE; }
+#else
+__device__ __forceinline__ int vg_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x / VG_WAVE)); }
+#endif
 
 enum vg_status {
     VG_OK = 0,
@@ -39,5 +48,19 @@ struct VgPrologue {
     int relu;             // apply max(x,0) first
     int per_group;        // samples per statistic group (n / per_group = group); ignored if scale==nullptr
 };
+
+// LDS-DMA: 4 bytes per lane from a per-lane global address straight into LDS at (wave-uniform base +
+// lane*4), no VGPR round trip (global_load_lds_dword).  vg_dma_wait() retires this wave's DMAs; a
+// barrier must follow before other waves read the bytes.
+#ifdef VG_EMU
+static inline void vg_dma4(const float* gsrc, float* lds_row_base) { lds_row_base[emu_tid % 64] = *gsrc; }
+static inline void vg_dma_wait() {}
+#else
+__device__ __forceinline__ void vg_dma4(const float* gsrc, float* lds_row_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_row_base, 4, 0, 0);
+}
+__device__ __forceinline__ void vg_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
 
 __host__ __device__ static inline int vg_cdiv(int a, int b) { return (a + b - 1) / b; }

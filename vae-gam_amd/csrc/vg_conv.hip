@@ -1,16 +1,24 @@
 // vg_conv.hip -- direct 3-D convolution kernels for the VAE-GAM encoder/decoder (gfx950).
 //
-// Three kernel families cover every conv / transposed-conv forward, data-gradient and
-// weight-gradient of vae_reg_GP.py:187-218 (see include/vaegam.h for the maths):
+// Two kernel families cover every conv / transposed-conv forward and data gradient of
+// vae_reg_GP.py:187-218 (see include/vaegam.h for the maths; weight gradients: vg_wgrad.hip):
 //   corr3d      strided correlation (stride 1/2, leading zero padding)
 //   tconv3d_s2  stride-2 transposed convolution in gather form (each thread owns a 2x2x2 output brick)
-//   wgrad3d     weight gradient, persistent blocks + deterministic second-stage reduction
 //
-// Channel counts are 1/8/16, so one GEMM dimension is at most 16: the kernels are register-tiled
-// fp32 VALU kernels (each thread holds all CO accumulators of a small output brick), weights come
-// in through the scalar path (wave-uniform, pre-packed [ci][tap][co]) and the input tile with its
-// halo is staged once per channel chunk in LDS, with the producer's ReLU / batch-norm affine
-// applied while staging (activations are stored pre-activation).
+// Channel counts are 1/8/16, so one GEMM dimension is at most 16: these are register-tiled fp32
+// VALU kernels.  A thread owns a small output brick x COT output channels (all accumulators in
+// VGPRs); weights arrive through the scalar path (wave-uniform, pre-packed [ci][tap][co]); the
+// input window of the brick is read straight into registers with the producer's ReLU / batch-norm
+// affine applied on the way (activations are stored pre-activation), and neighbouring threads'
+// overlapping windows are served by the CU's vector L1.
+//
+// Measured on MI355X (round 1, tools/layer_bench.py, convt5 forward at 128 x 8 x 39x47x33):
+// the first version staged the haloed input tile through LDS once per channel chunk (two barriers
+// per chunk, one wave per tile row): 785 us, of which 107 us was arithmetic -- the tile fill was
+// latency-bound (4 waves per block, 152-byte rows, <20 KB in flight per CU).  Reading the window
+// directly keeps 50-130 independent loads in flight per thread with no barrier and 2-4x the
+// occupancy.  LDS staging is kept where a tile is re-read many times by different lanes
+// (vg_wgrad.hip).
 #include "vg_common.h"
 #include "../../include/vaegam.h"
 
@@ -20,51 +28,18 @@ struct CorrParams {
     vg_conv_desc d;
     int TWG, TH, TD;            // threads of a block along w / h / d
     int tilesW, tilesH, tilesD;
-    int LD, LH, LW, LWp;        // LDS tile (per channel)
-    int CCH;                    // channels staged per chunk
 };
 
-// ------------------------------------------------------------------------------------------
-// staging: one wave per LDS row, lanes along w.  Applies prologue; zero outside the input.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ x,
-                                           const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-                                           const vg_conv_desc& d, int n, int c0, int cc,
-                                           int id0, int ih0, int iw0, int LD, int LH, int LW, int LWp) {
-    const int lane = threadIdx.x % VG_WAVE, wave = threadIdx.x / VG_WAVE, nwaves = blockDim.x / VG_WAVE;
-    const int rows = cc * LD * LH;
-    const int g = (in_scale != nullptr) ? n / d.per_group : 0;
-    for (int r = wave; r < rows; r += nwaves) {
-        const int hy = r % LH; const int t = r / LH; const int dz = t % LD; const int c = t / LD;
-        const int id = id0 + dz, ih = ih0 + hy, ci = c0 + c;
-        const bool row_ok = (id >= 0) && (id < d.ID) && (ih >= 0) && (ih < d.IH);
-        const float* src = x + (((size_t)n * d.CI + ci) * d.ID + (row_ok ? id : 0)) * (size_t)d.IH * d.IW
-                             + (size_t)(row_ok ? ih : 0) * d.IW;
-        float sc = 1.f, sh = 0.f;
-        if (in_scale != nullptr) { sc = in_scale[g * d.CI + ci]; sh = in_shift[g * d.CI + ci]; }
-        float* dst = lds + (size_t)r * LWp;
-        for (int wx = lane; wx < LW; wx += VG_WAVE) {
-            const int iw = iw0 + wx;
-            float v = 0.f;
-            if (row_ok && iw >= 0 && iw < d.IW) {
-                v = src[iw];
-                if (d.relu_in) v = fmaxf(v, 0.f);
-                v = fmaf(v, sc, sh);
-            }
-            dst[wx] = v;
-        }
-    }
-}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
 // ------------------------------------------------------------------------------------------
 // corr3d
 // ------------------------------------------------------------------------------------------
-template <int CO, int KD, int KH, int KW, int S, int TDt, int THt, int TW>
+template <int COT, int KD, int KH, int KW, int S, int TDt, int THt, int TW>
 __global__ void __launch_bounds__(256)
-corr3d_k(const float* __restrict__ x, const float* __restrict__ wpk, const float* __restrict__ bias,
+corr3d_direct_k(const float* __restrict__ x, const float* __restrict__ wpk, const float* __restrict__ bias,
          const float* __restrict__ in_scale, const float* __restrict__ in_shift,
          const float* __restrict__ mask_src, float* __restrict__ y, CorrParams p) {
-    VG_DYN_SMEM(float, lds);
     constexpr int KVOL = KD * KH * KW;
     constexpr int RW = (TW - 1) * S + KW;
     constexpr int RD = (TDt - 1) * S + KD;
@@ -72,15 +47,33 @@ corr3d_k(const float* __restrict__ x, const float* __restrict__ wpk, const float
     const vg_conv_desc& d = p.d;
     const int tid = threadIdx.x;
     const int n = blockIdx.y;
+    const int CO = d.CO;                         // all output channels; this block computes [co0, co0+COT)
+    const int co0 = blockIdx.z * COT;
     int tile = blockIdx.x;
     const int twi = tile % p.tilesW; tile /= p.tilesW;
     const int thi = tile % p.tilesH; const int tdi = tile / p.tilesH;
     const int wg = tid % p.TWG; const int thl = (tid / p.TWG) % p.TH; const int tdl = tid / (p.TWG * p.TH);
-    const bool active = tdl < p.TD;
-    const int od0 = tdi * p.TD * TDt, oh0 = thi * p.TH * THt, ow0 = twi * p.TWG * TW;
-    const int id0 = od0 * S - d.pad_d, ih0 = oh0 * S - d.pad_h, iw0 = ow0 * S - d.pad_w;
+    // first output of this thread's brick
+    const int od_t = (tdi * p.TD + tdl) * TDt, oh_t = (thi * p.TH + thl) * THt, ow_t = (twi * p.TWG + wg) * TW;
+    if (tdl >= p.TD || od_t >= d.OD || oh_t >= d.OH || ow_t >= d.OW) return;      // no barriers in this kernel
+    const int id_t = od_t * S - d.pad_d, ih_t = oh_t * S - d.pad_h, iw_t = ow_t * S - d.pad_w;
 
-    float acc[TDt][THt][TW][CO];
+    // window geometry is the same for every input channel: clamped row offsets / column indices and
+    // their validity (zero padding and tile overhang) are computed once
+    int roff[RD][RH]; bool rok[RD][RH];
+#pragma unroll
+    for (int dz = 0; dz < RD; ++dz)
+#pragma unroll
+        for (int hy = 0; hy < RH; ++hy) {
+            const int id = id_t + dz, ih = ih_t + hy;
+            rok[dz][hy] = id >= 0 && id < d.ID && ih >= 0 && ih < d.IH;
+            roff[dz][hy] = (clampi(id, 0, d.ID - 1) * d.IH + clampi(ih, 0, d.IH - 1)) * d.IW;
+        }
+    int cof[RW]; bool cok[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) { const int iw = iw_t + i; cok[i] = iw >= 0 && iw < d.IW; cof[i] = clampi(iw, 0, d.IW - 1); }
+
+    float acc[TDt][THt][TW][COT];
 #pragma unroll
     for (int a = 0; a < TDt; ++a)
 #pragma unroll
@@ -88,25 +81,257 @@ corr3d_k(const float* __restrict__ x, const float* __restrict__ wpk, const float
 #pragma unroll
             for (int j = 0; j < TW; ++j)
 #pragma unroll
-                for (int co = 0; co < CO; ++co) acc[a][b][j][co] = 0.f;
+                for (int co = 0; co < COT; ++co) acc[a][b][j][co] = 0.f;
 
+    const int g = (in_scale != nullptr) ? n / d.per_group : 0;
+    const float lo = d.relu_in ? 0.f : -__builtin_inff();            // max(v, lo): ReLU or identity
+    const size_t vol = (size_t)d.ID * d.IH * d.IW;
+    // The window is consumed one d-slab (RH x RW values) at a time; the NEXT slab's loads are issued
+    // before the current slab's arithmetic, so RH*RW independent loads are always in flight behind the
+    // FMAs (software pipeline over the flattened (channel, dz) sequence, two register buffers).
+    float buf[2][RH][RW];
+    const float* __restrict__ xbase = x + (size_t)n * d.CI * vol;
+#pragma unroll
+    for (int hy = 0; hy < RH; ++hy)
+#pragma unroll
+        for (int i = 0; i < RW; ++i) buf[0][hy][i] = xbase[roff[0][hy] + cof[i]];
+    for (int ci = 0; ci < d.CI; ++ci) {
+        const float* __restrict__ xc = xbase + (size_t)ci * vol;
+        const float* __restrict__ xn = xbase + (size_t)min(ci + 1, d.CI - 1) * vol;      // next channel (clamped)
+        const float* __restrict__ wc = wpk + (size_t)ci * KVOL * CO + co0;
+        float sc = 1.f, sh = 0.f;
+        if (in_scale != nullptr) { sc = in_scale[g * d.CI + ci]; sh = in_shift[g * d.CI + ci]; }
+#pragma unroll
+        for (int dz = 0; dz < RD; ++dz) {
+            // ---- prefetch the next slab
+            {
+                const float* src = (dz + 1 < RD) ? xc : xn;
+                const int dzn = (dz + 1 < RD) ? dz + 1 : 0;
+#pragma unroll
+                for (int hy = 0; hy < RH; ++hy)
+#pragma unroll
+                    for (int i = 0; i < RW; ++i) buf[(dz + 1) & 1][hy][i] = src[roff[dzn][hy] + cof[i]];
+            }
+            // ---- consume the current slab
+#pragma unroll
+            for (int hy = 0; hy < RH; ++hy) {
+                float seg[RW];
+#pragma unroll
+                for (int i = 0; i < RW; ++i) {
+                    const float v = fmaf(fmaxf(buf[dz & 1][hy][i], lo), sc, sh);
+                    seg[i] = (rok[dz][hy] && cok[i]) ? v : 0.f;               // zero padding outside the input
+                }
+#pragma unroll
+                for (int a = 0; a < TDt; ++a) {
+                    const int kd = dz - a * S;
+                    if (kd < 0 || kd >= KD) continue;
+#pragma unroll
+                    for (int b = 0; b < THt; ++b) {
+                        const int kh = hy - b * S;
+                        if (kh < 0 || kh >= KH) continue;
+#pragma unroll
+                        for (int kw = 0; kw < KW; ++kw) {
+                            const int t = (kd * KH + kh) * KW + kw;
+#pragma unroll
+                            for (int co = 0; co < COT; ++co) {
+                                const float wv = wc[t * CO + co];
+#pragma unroll
+                                for (int j = 0; j < TW; ++j)
+                                    acc[a][b][j][co] = fmaf(seg[j * S + kw], wv, acc[a][b][j][co]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (RD & 1) {                              // odd slab count: the prefetched slab 0 of the next channel sits in buf[1]
+#pragma unroll
+            for (int hy = 0; hy < RH; ++hy)
+#pragma unroll
+                for (int i = 0; i < RW; ++i) buf[0][hy][i] = buf[1][hy][i];
+        }
+    }
+    const size_t plane = (size_t)d.OH * d.OW;
+    // fused ReLU backward of the producer: fetch all mask values first (clamped, unconditional loads that
+    // stay in flight together), then apply + store
+    if (mask_src) {
+#pragma unroll
+        for (int a = 0; a < TDt; ++a) {
+            const int odc = min(od_t + a, d.OD - 1);
+#pragma unroll
+            for (int b = 0; b < THt; ++b) {
+                const int ohc = min(oh_t + b, d.OH - 1);
+                float m[COT][TW];
+#pragma unroll
+                for (int co = 0; co < COT; ++co) {
+                    const size_t base = (((size_t)n * CO + co0 + co) * d.OD + odc) * plane + (size_t)ohc * d.OW;
+#pragma unroll
+                    for (int j = 0; j < TW; ++j) m[co][j] = mask_src[base + min(ow_t + j, d.OW - 1)];
+                }
+#pragma unroll
+                for (int co = 0; co < COT; ++co)
+#pragma unroll
+                    for (int j = 0; j < TW; ++j)
+                        if (!(m[co][j] > 0.f)) acc[a][b][j][co] = -__builtin_inff();      // marked, zeroed below
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < TDt; ++a) {
+        const int od = od_t + a;
+        if (od >= d.OD) continue;
+#pragma unroll
+        for (int b = 0; b < THt; ++b) {
+            const int oh = oh_t + b;
+            if (oh >= d.OH) continue;
+#pragma unroll
+            for (int co = 0; co < COT; ++co) {
+                const float bv = bias ? bias[co0 + co] : 0.f;
+                const size_t base = (((size_t)n * CO + co0 + co) * d.OD + od) * plane + (size_t)oh * d.OW;
+#pragma unroll
+                for (int j = 0; j < TW; ++j) {
+                    const int ow = ow_t + j;
+                    if (ow < d.OW) {
+                        const float v = acc[a][b][j][co];
+                        y[base + ow] = (v == -__builtin_inff()) ? 0.f : v + bv;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int COT, int KD, int KH, int KW, int S, int TDt, int THt, int TW>
+int launch_corr(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias, const float* in_scale,
+                const float* in_shift, const float* mask_src, float* y, hipStream_t s) {
+    CorrParams p; p.d = *d;
+    const int gw = vg_cdiv(d->OW, TW), gh = vg_cdiv(d->OH, THt), gd = vg_cdiv(d->OD, TDt);
+    // a block covers a compact brick of outputs so that the overlapping input windows of its
+    // threads hit the CU's L1: all of w (up to 16 thread columns), then h, then d
+    p.TWG = gw < 16 ? gw : 16;
+    int rem = 256 / p.TWG;
+    p.TH = gh < rem ? gh : rem;
+    if (p.TH > 8 && gd > 1) p.TH = 8;
+    rem = 256 / (p.TWG * p.TH);
+    p.TD = gd < rem ? gd : rem;
+    if (p.TD < 1) p.TD = 1;
+    p.tilesW = vg_cdiv(gw, p.TWG); p.tilesH = vg_cdiv(gh, p.TH); p.tilesD = vg_cdiv(gd, p.TD);
+    if (d->CO % COT) { vg_set_error("corr3d: CO=%d not a multiple of %d", d->CO, COT); return VG_ERR_UNSUPPORTED; }
+    const int threads = vg_cdiv(p.TWG * p.TH * p.TD, VG_WAVE) * VG_WAVE;
+    dim3 grid(p.tilesW * p.tilesH * p.tilesD, d->N, d->CO / COT);
+    vg_launch(corr3d_direct_k<COT, KD, KH, KW, S, TDt, THt, TW>, grid, dim3(threads), 0, s,
+              x, wpk, bias, in_scale, in_shift, mask_src, y, p);
+    return vg_check_launch("corr3d_direct");
+}
+
+// ------------------------------------------------------------------------------------------
+// corr3d, plane-staged.  For every layer of the 41x49x35 network one block can cover ALL of H and W
+// of a few output planes, so the input a block needs per channel is LD whole input planes = ONE
+// contiguous span of the tensor.  That span is copied flat into LDS by LDS-DMA (global_load_lds_dword:
+// 256 contiguous bytes per wave-instruction, no VGPR round trip, every instruction of the chunk in
+// flight at once, ~5 instructions of address arithmetic each) and keeps the tensor's own row/plane
+// pitch; a thread then reads its window with immediate offsets, applying ReLU / batch-norm affine /
+// zero-padding masks on the way out of LDS.
+// (tools/micro/fill_bench.hip: this fill runs at 6-7 TB/s of tile bytes; a per-row gather of the same
+// tile 3.6 TB/s; the first per-row version with run-time row decoding was scalar-ALU bound at 0.6 TB/s.)
+// ------------------------------------------------------------------------------------------
+struct CorrPlaneParams {
+    vg_conv_desc d;
+    int TWG, TH, TD;            // threads along w / h / d; the block covers all of OW and OH
+    int tilesD;
+    int LD;                     // input planes per chunk-channel
+    int CCH;                    // channels per chunk
+    int ch_floats;              // LDS floats per channel (LD*IH*IW rounded up)
+};
+constexpr int PLANE_SLACK = 8;  // floats in front of the LDS buffer: a window may start at iw = -pad
+
+template <int COT, int KD, int KH, int KW, int S, int TDt, int THt, int TW>
+__global__ void __launch_bounds__(256)
+corr3d_plane_k(const float* __restrict__ x, const float* __restrict__ wpk, const float* __restrict__ bias,
+               const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+               const float* __restrict__ mask_src, float* __restrict__ y, CorrPlaneParams p) {
+    VG_DYN_SMEM(float, lds_raw);
+    float* lds = lds_raw + PLANE_SLACK;
+    constexpr int KVOL = KD * KH * KW;
+    constexpr int RW = (TW - 1) * S + KW;
+    constexpr int RD = (TDt - 1) * S + KD;
+    constexpr int RH = (THt - 1) * S + KH;
+    const vg_conv_desc& d = p.d;
+    const int tid = threadIdx.x;
+    const int lane = tid % VG_WAVE, wave = vg_wave_id();
+    const int n = blockIdx.y;
+    const int CO = d.CO;
+    const int co0 = blockIdx.z * COT;
+    const int tdi = blockIdx.x;
+    const int wg = tid % p.TWG; const int thl = (tid / p.TWG) % p.TH; const int tdl = tid / (p.TWG * p.TH);
+    const int od0 = tdi * p.TD * TDt;
+    const int od_t = od0 + tdl * TDt, oh_t = thl * THt, ow_t = wg * TW;
+    const bool active = tdl < p.TD && od_t < d.OD && oh_t < d.OH && ow_t < d.OW;
+    const int plane = d.IH * d.IW;
+    // input planes [ip0, ip0 + LD) clipped to the tensor; local plane l <-> input plane ip0 + l
+    const int ip0 = od0 * S - d.pad_d;
+    const int pl_lo = max(ip0, 0), pl_hi = min(ip0 + p.LD, d.ID);          // valid planes [pl_lo, pl_hi)
+    const int nfl = max(pl_hi - pl_lo, 0) * plane;                          // floats to copy per channel
+    const int dst0 = (pl_lo - ip0) * plane;                                 // where they land inside the channel slot
+
+    // this thread's window: LDS offsets of its rows (row index clamped, masked below) and validity
+    int roff[RD][RH]; bool rok[RD][RH]; bool cok[RW];
+    const int iw_t = ow_t * S - d.pad_w;
+#pragma unroll
+    for (int dz = 0; dz < RD; ++dz)
+#pragma unroll
+        for (int hy = 0; hy < RH; ++hy) {
+            const int id = od_t * S - d.pad_d + dz, ih = oh_t * S - d.pad_h + hy;
+            rok[dz][hy] = id >= 0 && id < d.ID && ih >= 0 && ih < d.IH;
+            const int lp = clampi(id - ip0, 0, p.LD - 1);
+            roff[dz][hy] = lp * plane + clampi(ih, 0, d.IH - 1) * d.IW + iw_t;
+        }
+#pragma unroll
+    for (int i = 0; i < RW; ++i) { const int iw = iw_t + i; cok[i] = iw >= 0 && iw < d.IW; }
+
+    float acc[TDt][THt][TW][COT];
+#pragma unroll
+    for (int a = 0; a < TDt; ++a)
+#pragma unroll
+        for (int b = 0; b < THt; ++b)
+#pragma unroll
+            for (int j = 0; j < TW; ++j)
+#pragma unroll
+                for (int co = 0; co < COT; ++co) acc[a][b][j][co] = 0.f;
+
+    const int g = (in_scale != nullptr) ? n / d.per_group : 0;
+    const float lo = d.relu_in ? 0.f : -__builtin_inff();
+    const size_t vol = (size_t)plane * d.ID;
+    const float* __restrict__ xsrc = x + (size_t)n * d.CI * vol + (size_t)pl_lo * plane;
     for (int c0 = 0; c0 < d.CI; c0 += p.CCH) {
         const int cc = min(p.CCH, d.CI - c0);
-        __syncthreads();
-        stage_tile(lds, x, in_scale, in_shift, d, n, c0, cc, id0, ih0, iw0, p.LD, p.LH, p.LW, p.LWp);
+        __syncthreads();                                  // previous chunk fully consumed
+        for (int c = 0; c < cc; ++c) {
+            const float* src = xsrc + (size_t)(c0 + c) * vol;
+            float* dst = lds + c * p.ch_floats + dst0;
+            for (int o = wave * VG_WAVE; o < nfl; o += blockDim.x)
+                if (o + lane < nfl) vg_dma4(src + o + lane, dst + o);
+        }
+        vg_dma_wait();
         __syncthreads();
         if (active) {
             for (int c = 0; c < cc; ++c) {
-                const float* __restrict__ wc = wpk + (size_t)(c0 + c) * KVOL * CO;
-                const float* tl = lds + ((size_t)(c * p.LD + tdl * TDt * S) * p.LH + thl * THt * S) * p.LWp + wg * TW * S;
+                const int ci = c0 + c;
+                const float* __restrict__ wc = wpk + (size_t)ci * KVOL * CO + co0;
+                float sc = 1.f, sh = 0.f;
+                if (in_scale != nullptr) { sc = in_scale[g * d.CI + ci]; sh = in_shift[g * d.CI + ci]; }
+                const float* tl = lds + c * p.ch_floats;
 #pragma unroll
                 for (int dz = 0; dz < RD; ++dz) {
 #pragma unroll
                     for (int hy = 0; hy < RH; ++hy) {
+                        const float* row = tl + roff[dz][hy];
                         float seg[RW];
-                        const float* row = tl + ((size_t)dz * p.LH + hy) * p.LWp;
 #pragma unroll
-                        for (int i = 0; i < RW; ++i) seg[i] = row[i];
+                        for (int i = 0; i < RW; ++i) {
+                            const float v = fmaf(fmaxf(row[i], lo), sc, sh);
+                            seg[i] = (rok[dz][hy] && cok[i]) ? v : 0.f;
+                        }
 #pragma unroll
                         for (int a = 0; a < TDt; ++a) {
                             const int kd = dz - a * S;
@@ -119,7 +344,7 @@ corr3d_k(const float* __restrict__ x, const float* __restrict__ wpk, const float
                                 for (int kw = 0; kw < KW; ++kw) {
                                     const int t = (kd * KH + kh) * KW + kw;
 #pragma unroll
-                                    for (int co = 0; co < CO; ++co) {
+                                    for (int co = 0; co < COT; ++co) {
                                         const float wv = wc[t * CO + co];
 #pragma unroll
                                         for (int j = 0; j < TW; ++j)
@@ -134,26 +359,47 @@ corr3d_k(const float* __restrict__ x, const float* __restrict__ wpk, const float
         }
     }
     if (!active) return;
-    const size_t plane = (size_t)d.OH * d.OW;
+    const size_t oplane = (size_t)d.OH * d.OW;
+    if (mask_src) {
+#pragma unroll
+        for (int a = 0; a < TDt; ++a) {
+            const int odc = min(od_t + a, d.OD - 1);
+#pragma unroll
+            for (int b = 0; b < THt; ++b) {
+                const int ohc = min(oh_t + b, d.OH - 1);
+                float m[COT][TW];
+#pragma unroll
+                for (int co = 0; co < COT; ++co) {
+                    const size_t base = (((size_t)n * CO + co0 + co) * d.OD + odc) * oplane + (size_t)ohc * d.OW;
+#pragma unroll
+                    for (int j = 0; j < TW; ++j) m[co][j] = mask_src[base + min(ow_t + j, d.OW - 1)];
+                }
+#pragma unroll
+                for (int co = 0; co < COT; ++co)
+#pragma unroll
+                    for (int j = 0; j < TW; ++j)
+                        if (!(m[co][j] > 0.f)) acc[a][b][j][co] = -__builtin_inff();
+            }
+        }
+    }
 #pragma unroll
     for (int a = 0; a < TDt; ++a) {
-        const int od = od0 + tdl * TDt + a;
+        const int od = od_t + a;
         if (od >= d.OD) continue;
 #pragma unroll
         for (int b = 0; b < THt; ++b) {
-            const int oh = oh0 + thl * THt + b;
+            const int oh = oh_t + b;
             if (oh >= d.OH) continue;
 #pragma unroll
-            for (int co = 0; co < CO; ++co) {
-                const float bv = bias ? bias[co] : 0.f;
-                const size_t base = (((size_t)n * CO + co) * d.OD + od) * plane + (size_t)oh * d.OW;
+            for (int co = 0; co < COT; ++co) {
+                const float bv = bias ? bias[co0 + co] : 0.f;
+                const size_t base = (((size_t)n * CO + co0 + co) * d.OD + od) * oplane + (size_t)oh * d.OW;
 #pragma unroll
                 for (int j = 0; j < TW; ++j) {
-                    const int ow = ow0 + wg * TW + j;
+                    const int ow = ow_t + j;
                     if (ow < d.OW) {
-                        float v = acc[a][b][j][co] + bv;
-                        if (mask_src) v = (mask_src[base + ow] > 0.f) ? v : 0.f;
-                        y[base + ow] = v;
+                        const float v = acc[a][b][j][co];
+                        y[base + ow] = (v == -__builtin_inff()) ? 0.f : v + bv;
                     }
                 }
             }
@@ -161,33 +407,37 @@ corr3d_k(const float* __restrict__ x, const float* __restrict__ wpk, const float
     }
 }
 
-template <int CO, int KD, int KH, int KW, int S, int TDt, int THt, int TW>
-int launch_corr(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias, const float* in_scale,
-                const float* in_shift, const float* mask_src, float* y, hipStream_t s) {
-    CorrParams p; p.d = *d;
+// plane-staged launch; returns -1 if the geometry does not fit (caller falls back to the direct kernel)
+template <int COT, int KD, int KH, int KW, int S, int TDt, int THt, int TW>
+int launch_corr_plane(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias, const float* in_scale,
+                      const float* in_shift, const float* mask_src, float* y, hipStream_t s) {
+    CorrPlaneParams p; p.d = *d;
     const int gw = vg_cdiv(d->OW, TW), gh = vg_cdiv(d->OH, THt), gd = vg_cdiv(d->OD, TDt);
-    p.TWG = gw < 16 ? gw : 16;
-    int rem = 256 / p.TWG;
-    p.TH = gh < rem ? gh : rem;
-    rem = 256 / (p.TWG * p.TH);
-    p.TD = gd < rem ? gd : rem;
-    if (p.TD < 1) p.TD = 1;
-    p.tilesW = vg_cdiv(gw, p.TWG); p.tilesH = vg_cdiv(gh, p.TH); p.tilesD = vg_cdiv(gd, p.TD);
-    p.LW = (p.TWG * TW - 1) * S + KW; p.LH = (p.TH * THt - 1) * S + KH; p.LD = (p.TD * TDt - 1) * S + KD;
-    p.LWp = p.LW | 1;                               // odd row pitch: rows interleave over the LDS banks
-    if ((p.LWp & 3) == 3) p.LWp += 2;               // pitch = 1 (mod 4)
-    const size_t per_ch = (size_t)p.LD * p.LH * p.LWp * sizeof(float);
-    int cch = (int)((size_t)40960 / per_ch);
+    if (gw * gh > 256) return -1;                        // one block must span all of H and W
+    p.TWG = gw; p.TH = gh;
+    const int plane = d->IH * d->IW;
+    const size_t budget = 48 * 1024;
+    int td = 256 / (gw * gh);
+    if (td > gd) td = gd;
+    for (; td >= 1; --td) {
+        const int LD = (td * TDt - 1) * S + KD;
+        if (((size_t)LD * plane + 64) * sizeof(float) + 64 <= budget) break;
+    }
+    if (td < 1) return -1;
+    p.TD = td; p.LD = (td * TDt - 1) * S + KD;
+    p.tilesD = vg_cdiv(gd, p.TD);
+    p.ch_floats = ((p.LD * plane + 63) / 64) * 64 + 64;  // slot per channel: whole 256-byte DMA groups + slack for window over-reads
+    int cch = (int)((budget - 64) / ((size_t)p.ch_floats * sizeof(float)));
     if (cch < 1) cch = 1;
     if (cch > d->CI) cch = d->CI;
     p.CCH = cch;
-    const size_t shmem = per_ch * cch;
-    if (shmem > 64 * 1024) { vg_set_error("corr3d: LDS tile of %zu bytes too large", shmem); return VG_ERR_UNSUPPORTED; }
+    const size_t shmem = (size_t)p.ch_floats * cch * sizeof(float) + (PLANE_SLACK + 64) * sizeof(float);
+    if (d->CO % COT) { vg_set_error("corr3d: CO=%d not a multiple of %d", d->CO, COT); return VG_ERR_UNSUPPORTED; }
     const int threads = vg_cdiv(p.TWG * p.TH * p.TD, VG_WAVE) * VG_WAVE;
-    dim3 grid(p.tilesW * p.tilesH * p.tilesD, d->N);
-    vg_launch(corr3d_k<CO, KD, KH, KW, S, TDt, THt, TW>, grid, dim3(threads), shmem, s,
+    dim3 grid(p.tilesD, d->N, d->CO / COT);
+    vg_launch(corr3d_plane_k<COT, KD, KH, KW, S, TDt, THt, TW>, grid, dim3(threads), shmem, s,
               x, wpk, bias, in_scale, in_shift, mask_src, y, p);
-    return vg_check_launch("corr3d");
+    return vg_check_launch("corr3d_plane");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -199,15 +449,13 @@ struct TconvParams {
     int TJW, TJH, TJD;
     int tilesW, tilesH, tilesD;
     int JD, JH, JW;             // number of j positions per dim
-    int LD, LH, LW, LWp, CCH;
 };
 
-template <int CO, int KD, int KH, int KW>
+template <int COT, int KD, int KH, int KW>
 __global__ void __launch_bounds__(256)
 tconv3d_s2_k(const float* __restrict__ x, const float* __restrict__ wpk, const float* __restrict__ bias,
              const float* __restrict__ in_scale, const float* __restrict__ in_shift,
              const float* __restrict__ mask_src, float* __restrict__ y, TconvParams p) {
-    VG_DYN_SMEM(float, lds);
     constexpr int KVOL = KD * KH * KW;
     constexpr int MD = (KD + 1) / 2, MH = (KH + 1) / 2, MW = (KW + 1) / 2;
     const vg_conv_desc& d = p.d;
@@ -216,13 +464,27 @@ tconv3d_s2_k(const float* __restrict__ x, const float* __restrict__ wpk, const f
     int tile = blockIdx.x;
     const int twi = tile % p.tilesW; tile /= p.tilesW;
     const int thi = tile % p.tilesH; const int tdi = tile / p.tilesH;
+    const int CO = d.CO;
+    const int co0 = blockIdx.z * COT;
     const int jwl = tid % p.TJW; const int jhl = (tid / p.TJW) % p.TJH; const int jdl = tid / (p.TJW * p.TJH);
-    const bool active = jdl < p.TJD;
-    const int jd0 = tdi * p.TJD, jh0 = thi * p.TJH, jw0 = twi * p.TJW;
-    // LDS tile origin in input coordinates: i = j0 - (M-1)
-    const int id0 = jd0 - (MD - 1), ih0 = jh0 - (MH - 1), iw0 = jw0 - (MW - 1);
+    const int jd = tdi * p.TJD + jdl, jh = thi * p.TJH + jhl, jw = twi * p.TJW + jwl;
+    if (jdl >= p.TJD || jd >= p.JD || jh >= p.JH || jw >= p.JW) return;           // no barriers in this kernel
 
-    float acc[2][2][2][CO];
+    // input i = j - m per dim: clamped offsets + validity, shared by all channels
+    int roff[MD][MH]; bool rok[MD][MH];
+#pragma unroll
+    for (int md = 0; md < MD; ++md)
+#pragma unroll
+        for (int mh = 0; mh < MH; ++mh) {
+            const int id = jd - md, ih = jh - mh;
+            rok[md][mh] = id >= 0 && id < d.ID && ih >= 0 && ih < d.IH;
+            roff[md][mh] = (clampi(id, 0, d.ID - 1) * d.IH + clampi(ih, 0, d.IH - 1)) * d.IW;
+        }
+    int cof[MW]; bool cok[MW];
+#pragma unroll
+    for (int mw = 0; mw < MW; ++mw) { const int iw = jw - mw; cok[mw] = iw >= 0 && iw < d.IW; cof[mw] = clampi(iw, 0, d.IW - 1); }
+
+    float acc[2][2][2][COT];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -230,51 +492,87 @@ tconv3d_s2_k(const float* __restrict__ x, const float* __restrict__ wpk, const f
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int co = 0; co < CO; ++co) acc[a][b][c][co] = 0.f;
+                for (int co = 0; co < COT; ++co) acc[a][b][c][co] = 0.f;
 
-    for (int c0 = 0; c0 < d.CI; c0 += p.CCH) {
-        const int cc = min(p.CCH, d.CI - c0);
-        __syncthreads();
-        stage_tile(lds, x, in_scale, in_shift, d, n, c0, cc, id0, ih0, iw0, p.LD, p.LH, p.LW, p.LWp);
-        __syncthreads();
-        if (active) {
-            for (int c = 0; c < cc; ++c) {
-                const float* __restrict__ wc = wpk + (size_t)(c0 + c) * KVOL * CO;
-                // local coordinate of input i = j - m is (jl - m + M - 1)
-                const float* tl = lds + ((size_t)(c * p.LD + jdl) * p.LH + jhl) * p.LWp + jwl;
+    const int g = (in_scale != nullptr) ? n / d.per_group : 0;
+    const float lo = d.relu_in ? 0.f : -__builtin_inff();
+    const size_t vol = (size_t)d.ID * d.IH * d.IW;
+    // software pipeline over channels: the next channel's window is in flight behind this channel's FMAs
+    float nxt[MD][MH][MW];
+    const float* __restrict__ xbase = x + (size_t)n * d.CI * vol;
 #pragma unroll
-                for (int md = 0; md < MD; ++md)
+    for (int md = 0; md < MD; ++md)
 #pragma unroll
-                    for (int mh = 0; mh < MH; ++mh)
+        for (int mh = 0; mh < MH; ++mh)
 #pragma unroll
-                        for (int mw = 0; mw < MW; ++mw) {
-                            const float xv = tl[((size_t)(MD - 1 - md) * p.LH + (MH - 1 - mh)) * p.LWp + (MW - 1 - mw)];
+            for (int mw = 0; mw < MW; ++mw) nxt[md][mh][mw] = xbase[roff[md][mh] + cof[mw]];
+    for (int ci = 0; ci < d.CI; ++ci) {
+        const float* __restrict__ xn = xbase + (size_t)min(ci + 1, d.CI - 1) * vol;
+        const float* __restrict__ wc = wpk + (size_t)ci * KVOL * CO + co0;
+        float sc = 1.f, sh = 0.f;
+        if (in_scale != nullptr) { sc = in_scale[g * d.CI + ci]; sh = in_shift[g * d.CI + ci]; }
+        float xin[MD][MH][MW];
 #pragma unroll
-                            for (int rd = 0; rd < 2; ++rd) {
-                                const int kd = rd + 2 * md;
-                                if (kd >= KD) continue;
+        for (int md = 0; md < MD; ++md)
 #pragma unroll
-                                for (int rh = 0; rh < 2; ++rh) {
-                                    const int kh = rh + 2 * mh;
-                                    if (kh >= KH) continue;
+            for (int mh = 0; mh < MH; ++mh)
 #pragma unroll
-                                    for (int rw = 0; rw < 2; ++rw) {
-                                        const int kw = rw + 2 * mw;
-                                        if (kw >= KW) continue;
-                                        const int t = (kd * KH + kh) * KW + kw;
+                for (int mw = 0; mw < MW; ++mw) {
+                    const float v = fmaf(fmaxf(nxt[md][mh][mw], lo), sc, sh);
+                    xin[md][mh][mw] = (rok[md][mh] && cok[mw]) ? v : 0.f;
+                    nxt[md][mh][mw] = xn[roff[md][mh] + cof[mw]];
+                }
 #pragma unroll
-                                        for (int co = 0; co < CO; ++co)
-                                            acc[rd][rh][rw][co] = fmaf(xv, wc[t * CO + co], acc[rd][rh][rw][co]);
-                                    }
-                                }
+        for (int md = 0; md < MD; ++md)
+#pragma unroll
+            for (int mh = 0; mh < MH; ++mh)
+#pragma unroll
+                for (int mw = 0; mw < MW; ++mw) {
+                    const float xv = xin[md][mh][mw];
+#pragma unroll
+                    for (int rd = 0; rd < 2; ++rd) {
+                        const int kd = rd + 2 * md;
+                        if (kd >= KD) continue;
+#pragma unroll
+                        for (int rh = 0; rh < 2; ++rh) {
+                            const int kh = rh + 2 * mh;
+                            if (kh >= KH) continue;
+#pragma unroll
+                            for (int rw = 0; rw < 2; ++rw) {
+                                const int kw = rw + 2 * mw;
+                                if (kw >= KW) continue;
+                                const int t = (kd * KH + kh) * KW + kw;
+#pragma unroll
+                                for (int co = 0; co < COT; ++co)
+                                    acc[rd][rh][rw][co] = fmaf(xv, wc[t * CO + co], acc[rd][rh][rw][co]);
                             }
                         }
+                    }
+                }
+    }
+    const size_t plane = (size_t)d.OH * d.OW;
+    if (mask_src) {                                  // batched, clamped mask fetch (see corr3d_k)
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int odc = min(max(2 * jd + rd - d.pad_d, 0), d.OD - 1);
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) {
+                const int ohc = min(max(2 * jh + rh - d.pad_h, 0), d.OH - 1);
+                float m[COT][2];
+#pragma unroll
+                for (int co = 0; co < COT; ++co) {
+                    const size_t base = (((size_t)n * CO + co0 + co) * d.OD + odc) * plane + (size_t)ohc * d.OW;
+#pragma unroll
+                    for (int rw = 0; rw < 2; ++rw) m[co][rw] = mask_src[base + min(max(2 * jw + rw - d.pad_w, 0), d.OW - 1)];
+                }
+#pragma unroll
+                for (int co = 0; co < COT; ++co)
+#pragma unroll
+                    for (int rw = 0; rw < 2; ++rw)
+                        if (!(m[co][rw] > 0.f)) acc[rd][rh][rw][co] = -__builtin_inff();
             }
         }
     }
-    if (!active) return;
-    const int jd = jd0 + jdl, jh = jh0 + jhl, jw = jw0 + jwl;
-    const size_t plane = (size_t)d.OH * d.OW;
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) {
         const int od = 2 * jd + rd - d.pad_d;
@@ -284,16 +582,15 @@ tconv3d_s2_k(const float* __restrict__ x, const float* __restrict__ wpk, const f
             const int oh = 2 * jh + rh - d.pad_h;
             if (oh < 0 || oh >= d.OH) continue;
 #pragma unroll
-            for (int co = 0; co < CO; ++co) {
-                const float bv = bias ? bias[co] : 0.f;
-                const size_t base = (((size_t)n * CO + co) * d.OD + od) * plane + (size_t)oh * d.OW;
+            for (int co = 0; co < COT; ++co) {
+                const float bv = bias ? bias[co0 + co] : 0.f;
+                const size_t base = (((size_t)n * CO + co0 + co) * d.OD + od) * plane + (size_t)oh * d.OW;
 #pragma unroll
                 for (int rw = 0; rw < 2; ++rw) {
                     const int ow = 2 * jw + rw - d.pad_w;
                     if (ow >= 0 && ow < d.OW) {
-                        float v = acc[rd][rh][rw][co] + bv;
-                        if (mask_src) v = (mask_src[base + ow] > 0.f) ? v : 0.f;
-                        y[base + ow] = v;
+                        const float v = acc[rd][rh][rw][co];
+                        y[base + ow] = (v == -__builtin_inff()) ? 0.f : v + bv;
                     }
                 }
             }
@@ -301,10 +598,9 @@ tconv3d_s2_k(const float* __restrict__ x, const float* __restrict__ wpk, const f
     }
 }
 
-template <int CO, int KD, int KH, int KW>
+template <int COT, int KD, int KH, int KW>
 int launch_tconv(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias, const float* in_scale,
                  const float* in_shift, const float* mask_src, float* y, hipStream_t s) {
-    constexpr int MD = (KD + 1) / 2, MH = (KH + 1) / 2, MW = (KW + 1) / 2;
     TconvParams p; p.d = *d;
     p.JD = (d->OD + d->pad_d + 1) / 2; p.JH = (d->OH + d->pad_h + 1) / 2; p.JW = (d->OW + d->pad_w + 1) / 2;
     p.TJW = p.JW < 32 ? p.JW : 32;
@@ -314,18 +610,10 @@ int launch_tconv(const vg_conv_desc* d, const float* x, const float* wpk, const 
     p.TJD = p.JD < rem ? p.JD : rem;
     if (p.TJD < 1) p.TJD = 1;
     p.tilesW = vg_cdiv(p.JW, p.TJW); p.tilesH = vg_cdiv(p.JH, p.TJH); p.tilesD = vg_cdiv(p.JD, p.TJD);
-    p.LW = p.TJW + MW - 1; p.LH = p.TJH + MH - 1; p.LD = p.TJD + MD - 1;
-    p.LWp = p.LW | 1;
-    const size_t per_ch = (size_t)p.LD * p.LH * p.LWp * sizeof(float);
-    int cch = (int)((size_t)40960 / per_ch);
-    if (cch < 1) cch = 1;
-    if (cch > d->CI) cch = d->CI;
-    p.CCH = cch;
-    const size_t shmem = per_ch * cch;
-    if (shmem > 64 * 1024) { vg_set_error("tconv3d_s2: LDS tile of %zu bytes too large", shmem); return VG_ERR_UNSUPPORTED; }
+    if (d->CO % COT) { vg_set_error("tconv3d_s2: CO=%d not a multiple of %d", d->CO, COT); return VG_ERR_UNSUPPORTED; }
     const int threads = vg_cdiv(p.TJW * p.TJH * p.TJD, VG_WAVE) * VG_WAVE;
-    dim3 grid(p.tilesW * p.tilesH * p.tilesD, d->N);
-    vg_launch(tconv3d_s2_k<CO, KD, KH, KW>, grid, dim3(threads), shmem, s,
+    dim3 grid(p.tilesW * p.tilesH * p.tilesD, d->N, d->CO / COT);
+    vg_launch(tconv3d_s2_k<COT, KD, KH, KW>, grid, dim3(threads), 0, s,
               x, wpk, bias, in_scale, in_shift, mask_src, y, p);
     return vg_check_launch("tconv3d_s2");
 }
@@ -360,21 +648,30 @@ extern "C" int vg_corr3d(const vg_conv_desc* d, const float* x, const float* wpk
         return VG_ERR_ARG;
     }
     hipStream_t s = (hipStream_t)stream;
-    const int key = d->CO * 100000 + d->KD * 10000 + d->KH * 1000 + d->KW * 100 + d->stride;
-#define CORR_CASE(CO, KD, KH, KW, S, TDt, THt, TW) \
-    case CO * 100000 + KD * 10000 + KH * 1000 + KW * 100 + S: \
-        return launch_corr<CO, KD, KH, KW, S, TDt, THt, TW>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s);
-    switch (key) {
-        CORR_CASE(1, 3, 3, 3, 1, 2, 2, 4)
-        CORR_CASE(8, 3, 3, 3, 1, 1, 1, 4)
-        CORR_CASE(16, 3, 3, 3, 1, 1, 1, 4)
-        CORR_CASE(8, 3, 3, 3, 2, 1, 1, 4)
-        CORR_CASE(16, 3, 3, 3, 2, 1, 1, 2)
-        CORR_CASE(8, 5, 3, 3, 2, 1, 1, 4)
-        CORR_CASE(8, 4, 4, 4, 2, 1, 1, 4)
-        default: break;
+    // "small" launches (few output positions) trade register tiling for parallelism: fewer outputs and
+    // fewer output channels per thread, the channel groups spread over grid.z
+    const long long pos = (long long)d->N * d->OD * d->OH * d->OW;
+    const bool small = pos * d->CO < (long long)1536 * 1024;
+    const bool k333 = d->KD == 3 && d->KH == 3 && d->KW == 3;
+#define CORR(COT, KD, KH, KW, S, TDt, THt, TW) \
+    return launch_corr<COT, KD, KH, KW, S, TDt, THt, TW>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s)
+#define CORR_LDS(COT, KD, KH, KW, S, TDt, THt, TW) \
+    { int r_ = launch_corr_plane<COT, KD, KH, KW, S, TDt, THt, TW>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); \
+      if (r_ >= 0) return r_; \
+      return launch_corr<COT, KD, KH, KW, S, TDt, THt, TW>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); }
+    if (k333 && d->stride == 1) {
+        if (d->CO == 1) CORR_LDS(1, 3, 3, 3, 1, 2, 2, 4);
+        if (d->CO % 8 == 0 && !small) CORR_LDS(8, 3, 3, 3, 1, 1, 1, 4);
+        if (d->CO % 4 == 0 && small) CORR(4, 3, 3, 3, 1, 1, 1, 2);
     }
-#undef CORR_CASE
+    if (k333 && d->stride == 2) {
+        if (d->CO % 8 == 0 && !small) CORR_LDS(8, 3, 3, 3, 2, 1, 1, 4);
+        if (d->CO % 4 == 0 && small) CORR(4, 3, 3, 3, 2, 1, 1, 2);
+    }
+    if (d->KD == 5 && d->KH == 3 && d->KW == 3 && d->stride == 2 && d->CO % 8 == 0) CORR_LDS(8, 5, 3, 3, 2, 1, 1, 4);
+    if (d->KD == 4 && d->KH == 4 && d->KW == 4 && d->stride == 2 && d->CO % 8 == 0) CORR_LDS(8, 4, 4, 4, 2, 1, 1, 4);
+#undef CORR
+#undef CORR_LDS
     vg_set_error("vg_corr3d: no kernel instance for CO=%d k=%dx%dx%d stride=%d", d->CO, d->KD, d->KH, d->KW, d->stride);
     return VG_ERR_UNSUPPORTED;
 }
@@ -388,18 +685,17 @@ extern "C" int vg_tconv3d_s2(const vg_conv_desc* d, const float* x, const float*
         vg_set_error("vg_tconv3d_s2: in_scale/in_shift/per_group inconsistent"); return VG_ERR_ARG;
     }
     hipStream_t s = (hipStream_t)stream;
-    const int key = d->CO * 1000 + d->KD * 100 + d->KH * 10 + d->KW;
-#define TCONV_CASE(CO, KD, KH, KW) \
-    case CO * 1000 + KD * 100 + KH * 10 + KW: \
-        return launch_tconv<CO, KD, KH, KW>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s);
-    switch (key) {
-        TCONV_CASE(8, 3, 3, 3)
-        TCONV_CASE(16, 3, 3, 3)
-        TCONV_CASE(8, 5, 3, 3)
-        TCONV_CASE(8, 4, 4, 4)
-        default: break;
+    const long long pos = (long long)d->N * d->OD * d->OH * d->OW;
+    const bool small = pos * d->CO < (long long)8 * 1024 * 1024;
+#define TCONV(COT, KD, KH, KW) \
+    return launch_tconv<COT, KD, KH, KW>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s)
+    if (d->KD == 3 && d->KH == 3 && d->KW == 3) {
+        if (d->CO % 8 == 0 && !small) TCONV(8, 3, 3, 3);
+        if (d->CO % 4 == 0 && small) TCONV(4, 3, 3, 3);
     }
-#undef TCONV_CASE
+    if (d->KD == 5 && d->KH == 3 && d->KW == 3 && d->CO % 8 == 0) TCONV(8, 5, 3, 3);
+    if (d->KD == 4 && d->KH == 4 && d->KW == 4 && d->CO % 8 == 0) TCONV(8, 4, 4, 4);
+#undef TCONV
     vg_set_error("vg_tconv3d_s2: no kernel instance for CO=%d k=%dx%dx%d", d->CO, d->KD, d->KH, d->KW);
     return VG_ERR_UNSUPPORTED;
 }

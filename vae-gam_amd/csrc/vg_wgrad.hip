@@ -62,7 +62,7 @@ wgrad_own_k(const float* __restrict__ a, const float* __restrict__ b, const floa
 
     float* atile = lds;
     float* btile = lds + p.b_off;
-    const int lane = tid % VG_WAVE, wave = tid / VG_WAVE, nwaves = blockDim.x / VG_WAVE;
+    const int lane = tid % VG_WAVE, wave = vg_wave_id(), nwaves = blockDim.x / VG_WAVE;
     const int tiles = p.tilesW * p.tilesH * p.tilesD;
 
     for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
@@ -72,42 +72,80 @@ wgrad_own_k(const float* __restrict__ a, const float* __restrict__ b, const floa
         const int pd0 = tdi * p.TPD, ph0 = thi * p.TPH, pw0 = twi * TPW;
         const int g = (in_scale != nullptr) ? n / d.per_group : 0;
         __syncthreads();
-        // ---- stage a tile: [CA][LD][LH][LWp], zero outside, prologue if it belongs to a
+        // ---- stage a tile: [CA][LD][LH][LWp], zero outside, prologue if it belongs to a.
+        // A wave takes groups of U consecutive rows (U independent global loads in flight); the row's
+        // (c, dz, hy) is carried incrementally: no scalar div/mod per row.
         {
+            constexpr int U = 4;
             const int ad0 = pd0 * S - d.pad_d, ah0 = ph0 * S - d.pad_h, aw0 = pw0 * S - d.pad_w;
             const int rows = CA * p.LD * p.LH;
-            for (int r = wave; r < rows; r += nwaves) {
-                const int hy = r % p.LH; const int t = r / p.LH; const int dz = t % p.LD; const int c = t / p.LD;
-                const int id = ad0 + dz, ih = ah0 + hy;
-                const bool ok = id >= 0 && id < d.AD && ih >= 0 && ih < d.AH;
-                const float* src = a + (((size_t)n * CA + c) * d.AD + (ok ? id : 0)) * (size_t)d.AH * d.AW + (size_t)(ok ? ih : 0) * d.AW;
-                float sc = 1.f, sh = 0.f; int rl = 0;
-                if (d.pro_on_a) { rl = d.relu_in; if (in_scale) { sc = in_scale[g * CA + c]; sh = in_shift[g * CA + c]; } }
-                float* dst = atile + (size_t)r * p.LWp;
+            const size_t aplane = (size_t)d.AH * d.AW;
+            const int rl = d.pro_on_a ? d.relu_in : 0;
+            int c = 0, dz = 0, hy = wave * U;
+            while (hy >= p.LH) { hy -= p.LH; if (++dz == p.LD) { dz = 0; ++c; } }
+            for (int r0 = wave * U; r0 < rows; r0 += nwaves * U) {
+                const float* src[U]; float sc[U], sh[U]; bool ok[U];
+                int cu = c, dzu = dz, hyu = hy;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int cc_ = cu < CA ? cu : 0;
+                    const int id = ad0 + dzu, ih = ah0 + hyu;
+                    ok[u] = r0 + u < rows && id >= 0 && id < d.AD && ih >= 0 && ih < d.AH;
+                    src[u] = a + (((size_t)n * CA + cc_) * d.AD + (ok[u] ? id : 0)) * aplane + (size_t)(ok[u] ? ih : 0) * d.AW;
+                    sc[u] = 1.f; sh[u] = 0.f;
+                    if (d.pro_on_a && in_scale) { sc[u] = in_scale[g * CA + cc_]; sh[u] = in_shift[g * CA + cc_]; }
+                    if (++hyu == p.LH) { hyu = 0; if (++dzu == p.LD) { dzu = 0; ++cu; } }
+                }
                 for (int wx = lane; wx < p.LW; wx += VG_WAVE) {
                     const int iw = aw0 + wx;
-                    float v = 0.f;
-                    if (ok && iw >= 0 && iw < d.AW) v = apply_pro(src[iw], rl, sc, sh);
-                    dst[wx] = v;
+                    const bool cok = iw >= 0 && iw < d.AW;
+                    const int iwc = min(max(iw, 0), d.AW - 1);       // valid address: unconditional loads stay in flight
+                    float v[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) v[u] = src[u][iwc];
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (r0 + u < rows) atile[(size_t)(r0 + u) * p.LWp + wx] = (ok[u] && cok) ? apply_pro(v[u], rl, sc[u], sh[u]) : 0.f;
                 }
+                hy += nwaves * U;
+                while (hy >= p.LH) { hy -= p.LH; if (++dz == p.LD) { dz = 0; ++c; } }
             }
         }
-        // ---- stage b tile: [TPD][TPH][TPW][CB] (cb fastest), zero outside
+        // ---- stage b tile: [TPD][TPH][TPW][CB] (cb fastest), zero outside; rows ordered (c, dz, hy)
         {
+            constexpr int U = 4;
             const int rows = CB * p.TPD * p.TPH;
-            for (int r = wave; r < rows; r += nwaves) {
-                const int hy = r % p.TPH; const int t = r / p.TPH; const int dz = t % p.TPD; const int c = t / p.TPD;
-                const int pd = pd0 + dz, ph = ph0 + hy;
-                const bool ok = pd < d.PD && ph < d.PH;
-                const float* src = b + (((size_t)n * CB + c) * d.PD + (ok ? pd : 0)) * (size_t)d.PH * d.PW + (size_t)(ok ? ph : 0) * d.PW;
-                float sc = 1.f, sh = 0.f; int rl = 0;
-                if (!d.pro_on_a) { rl = d.relu_in; if (in_scale) { sc = in_scale[g * CB + c]; sh = in_shift[g * CB + c]; } }
+            const size_t bplane = (size_t)d.PH * d.PW;
+            const int rl = d.pro_on_a ? 0 : d.relu_in;
+            int c = 0, dz = 0, hy = wave * U;
+            while (hy >= p.TPH) { hy -= p.TPH; if (++dz == p.TPD) { dz = 0; ++c; } }
+            for (int r0 = wave * U; r0 < rows; r0 += nwaves * U) {
+                const float* src[U]; float sc[U], sh[U]; bool ok[U]; int dsto[U];
+                int cu = c, dzu = dz, hyu = hy;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int cc_ = cu < CB ? cu : 0;
+                    const int pd = pd0 + dzu, ph = ph0 + hyu;
+                    ok[u] = r0 + u < rows && pd < d.PD && ph < d.PH;
+                    src[u] = b + (((size_t)n * CB + cc_) * d.PD + (ok[u] ? pd : 0)) * bplane + (size_t)(ok[u] ? ph : 0) * d.PW;
+                    sc[u] = 1.f; sh[u] = 0.f;
+                    if (!d.pro_on_a && in_scale) { sc[u] = in_scale[g * CB + cc_]; sh[u] = in_shift[g * CB + cc_]; }
+                    dsto[u] = (dzu * p.TPH + hyu) * TPW * CB + cc_;
+                    if (++hyu == p.TPH) { hyu = 0; if (++dzu == p.TPD) { dzu = 0; ++cu; } }
+                }
                 for (int wx = lane; wx < TPW; wx += VG_WAVE) {
                     const int pw = pw0 + wx;
-                    float v = 0.f;
-                    if (ok && pw < d.PW) v = apply_pro(src[pw], rl, sc, sh);
-                    btile[((size_t)(dz * p.TPH + hy) * TPW + wx) * CB + c] = v;
+                    const bool cok = pw < d.PW;
+                    const int pwc = min(pw, d.PW - 1);
+                    float v[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) v[u] = src[u][pwc];
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        if (r0 + u < rows) btile[(size_t)dsto[u] + (size_t)wx * CB] = (ok[u] && cok) ? apply_pro(v[u], rl, sc[u], sh[u]) : 0.f;
                 }
+                hy += nwaves * U;
+                while (hy >= p.TPH) { hy -= p.TPH; if (++dz == p.TPD) { dz = 0; ++c; } }
             }
         }
         __syncthreads();
@@ -119,8 +157,13 @@ wgrad_own_k(const float* __restrict__ a, const float* __restrict__ b, const floa
 #pragma unroll
                     for (int pw = 0; pw < TPW; ++pw) {
                         float bv[CBT];
+                        if (CBT == 4) {                       // b tile is [p][cb], 16-byte aligned groups of 4 channels
+                            const float4 t4 = *reinterpret_cast<const float4*>(brow + pw * CB);
+                            bv[0] = t4.x; bv[1] = t4.y; bv[2] = t4.z; bv[3] = t4.w;
+                        } else {
 #pragma unroll
-                        for (int c = 0; c < CBT; ++c) bv[c] = brow[pw * CB + c];
+                            for (int c = 0; c < CBT; ++c) bv[c] = brow[pw * CB + c];
+                        }
 #pragma unroll
                         for (int i = 0; i < NKH; ++i) {
 #pragma unroll
@@ -245,7 +288,10 @@ wgrad_wide_k(const float* __restrict__ a, const float* __restrict__ b, const flo
             float sc = 1.f, sh = 0.f; int rl = 0;
             if (!d.pro_on_a) { rl = d.relu_in; if (in_scale) { sc = in_scale[g * CB + c]; sh = in_shift[g * CB + c]; } }
 #pragma unroll
-            for (int j = 0; j < TW; ++j) bv[c][j] = (pw0 + j < d.PW) ? apply_pro(src[pw0 + j], rl, sc, sh) : 0.f;
+            for (int j = 0; j < TW; ++j) {                   // clamped address + select: loads stay unconditional
+                const float t = src[min(pw0 + j, d.PW - 1)];
+                bv[c][j] = (pw0 + j < d.PW) ? apply_pro(t, rl, sc, sh) : 0.f;
+            }
         }
         float sca = 1.f, sha = 0.f; int rla = 0;
         if (d.pro_on_a) { rla = d.relu_in; if (in_scale) { sca = in_scale[g]; sha = in_shift[g]; } }
@@ -256,7 +302,10 @@ wgrad_wide_k(const float* __restrict__ a, const float* __restrict__ b, const flo
                 const float* src = a + (((size_t)n * d.AD + (pd + kd)) * d.AH + (ph + kh)) * (size_t)d.AW;
                 float seg[RW];
 #pragma unroll
-                for (int i = 0; i < RW; ++i) seg[i] = (pw0 + i < d.AW) ? apply_pro(src[pw0 + i], rla, sca, sha) : 0.f;
+                for (int i = 0; i < RW; ++i) {
+                    const float t = src[min(pw0 + i, d.AW - 1)];
+                    seg[i] = (pw0 + i < d.AW) ? apply_pro(t, rla, sca, sha) : 0.f;
+                }
 #pragma unroll
                 for (int kw = 0; kw < KW; ++kw)
 #pragma unroll

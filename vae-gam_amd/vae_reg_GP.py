@@ -123,6 +123,8 @@ class VAE(nn.Module):
         self.log_maps = False          # per-forward image logging of the reference; opt-in
         self._hrf_cache = {}
         self._glm_f32 = None
+        self.use_hip_graph = False     # capture the train step into a hipGraph (bench / long runs)
+        self._graphs = {}
 
     # ------------------------------------------------------------------ construction helpers
     _GAIN_PREFIXES = ('sa_', 'logstd_', 'qu_m_', 'qu_S_', 'logkvar_', 'logls_')
@@ -381,14 +383,56 @@ class VAE(nn.Module):
         return ids, covariates, x
 
     def train_step(self, ids, covariates, x, noise=None):
-        """One iteration of train_epoch's body (vae_reg_GP.py:425-429); returns the loss tensor (1,)."""
-        loss = self.forward(ids, covariates, x, 'train', train_mode=True, noise=noise)
+        """One iteration of train_epoch's body (vae_reg_GP.py:425-429); returns the loss tensor (1,).
+        With `self.use_hip_graph` the whole step (zero-grad, forward, backward, gradient all-reduce,
+        fused Adam: a few hundred launches) is captured once per batch shape into a hipGraph and
+        replayed; the host then only copies the minibatch into the graph's input buffers."""
+        if self.use_hip_graph and noise is None and x.is_cuda:
+            g = self._graphs.get(tuple(x.shape))
+            if g is None:
+                g = self._capture_step(ids, covariates, x)
+            if g is not False:
+                g['x'].copy_(x, non_blocking=True); g['cov'].copy_(covariates, non_blocking=True)
+                self.optimizer.prepare_step_scalars()
+                g['graph'].replay()
+                return g['loss']
+        return self._train_step_eager(ids, covariates, x, noise)
+
+    def _train_step_eager(self, ids, covariates, x, noise=None, advance=True):
         self.optimizer.zero_grad()
+        loss = self.forward(ids, covariates, x, 'train', train_mode=True, noise=noise)
         loss.backward()
         if self.dp is not None:
             self.dp.allreduce_grads(self.optimizer.flat_grads())
-        self.optimizer.step()
+        if advance:
+            self.optimizer.prepare_step_scalars()
+        self.optimizer.apply_update()
         return loss.detach()
+
+    def _capture_step(self, ids, covariates, x):
+        """Capture the train step for this batch shape; falls back to eager launches (and says so) if an
+        operator in the step refuses stream capture."""
+        import warnings
+        key = tuple(x.shape)
+        st = {'x': x.clone(), 'cov': covariates.clone(), 'ids': ids.clone()}
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                       # warm-up on a side stream (allocator, lazy inits)
+                for _ in range(2):
+                    self._train_step_eager(st['ids'], st['cov'], st['x'])
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            self.optimizer.prepare_step_scalars()
+            with torch.cuda.graph(graph):
+                st['loss'] = self._train_step_eager(st['ids'], st['cov'], st['x'], advance=False)
+            st['graph'] = graph
+            self._graphs[key] = st
+        except Exception as e:                                  # noqa: BLE001
+            warnings.warn('hipGraph capture of the train step failed (%s: %s); running eager launches' % (type(e).__name__, e))
+            self._graphs[key] = False
+            torch.cuda.synchronize()
+        return self._graphs[key]
 
     def train_epoch(self, train_loader):
         self.train()
