@@ -8,6 +8,10 @@ for the host to debug index arithmetic; tests inject that handle explicitly thro
 import ctypes
 import os
 
+import torch  # noqa: F401  -- MUST be imported before the kernel library is dlopen'ed: torch ships its own
+#                      libamdhip64; loading ours first would put two HIP runtimes in the process and every
+#                      stream / pointer handed across would be foreign ("no ROCm-capable device")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = 'libvaegam_hip.so'
 
