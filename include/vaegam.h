@@ -116,6 +116,11 @@ int vg_gam_elbo_bwd(const float* logits, const float* gain, const float* x, cons
                     int32_t C, int32_t B, int64_t V, void* ws,
                     float* d_logits, float* d_gain, double* d_eps, void* stream);
 
+/* batched lower Cholesky factor of [batch][n][n] float64 SPD matrices (n <= 128), one workgroup per matrix
+ * in LDS.  Replaces the Cholesky inside MultivariateNormal(beta_mean, beta_cov + 1e-5 I) (vae_reg_GP.py:368)
+ * and MultivariateNormal(qu_m, qu_S) (gp.py:51); unlike hipSOLVER's potrf it can be captured into a hipGraph. */
+int vg_cholesky_f64(const double* a, double* l, int32_t batch, int32_t n, void* stream);
+
 /* fused Adam (torch.optim.Adam defaults, vae_reg_GP.py:179,429) over one flat buffer:
  * p,g,m,v: n elements of fp32 (is_f64 = 0) or fp64 (is_f64 = 1).  step_size = lr/(1-b1^t),
  * bc2_sqrt = sqrt(1-b2^t) are passed as device scalars [2] so a captured graph can replay

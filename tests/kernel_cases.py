@@ -131,3 +131,18 @@ def run_adam_case(dev, dtype, n=5000, steps=3, seed=0):
         ops.adam_step_(p, gr.to(dev), m, v, 0.9, 0.999, 1e-8, sc)
     tol = 1e-6 if dtype == torch.float32 else 1e-12
     np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=tol, atol=tol)
+
+
+def run_cholesky_case(dev, batch=3, n=32, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    r = torch.randn(batch, n, n, generator=g, dtype=torch.float64)
+    a = r @ r.transpose(1, 2) + 0.5 * torch.eye(n, dtype=torch.float64)
+    a_ref = a.clone().requires_grad_(True)
+    l_ref = torch.linalg.cholesky(a_ref)
+    w = torch.randn(batch, n, n, generator=g, dtype=torch.float64)
+    (ga_ref,) = torch.autograd.grad((l_ref * w).sum(), a_ref)
+    a_d = a.to(dev).clone().requires_grad_(True)
+    l = ops.cholesky(a_d)
+    np.testing.assert_allclose(l.detach().cpu().numpy(), l_ref.detach().numpy(), rtol=1e-10, atol=1e-10)
+    (ga,) = torch.autograd.grad((l * w.to(dev)).sum(), a_d)
+    np.testing.assert_allclose(ga.cpu().numpy(), ga_ref.numpy(), rtol=1e-8, atol=1e-8)

@@ -54,3 +54,8 @@ def test_gam_elbo_no_covariates():
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
 def test_adam(dtype):
     K.run_adam_case('cpu', dtype)
+
+
+@pytest.mark.parametrize('n', [6, 32, 64])
+def test_cholesky(n):
+    K.run_cholesky_case('cpu', batch=3, n=n)

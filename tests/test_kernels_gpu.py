@@ -67,3 +67,8 @@ def test_library_refuses_bad_shapes():
     x = torch.zeros(1, 8, 5, 5, 5, device='cuda'); w = torch.zeros(3, 8, 3, 3, 3, device='cuda')
     with pytest.raises(_lib.VgError):
         ops.conv_forward(x, ops.pack_weight(w, spec, 'fwd'), None, spec)
+
+
+@pytest.mark.parametrize('n', [6, 32, 64])
+def test_cholesky(n):
+    K.run_cholesky_case('cuda', batch=3, n=n)

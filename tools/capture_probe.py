@@ -34,7 +34,9 @@ def probe(name, fn):
 noise = m.draw_noise(B, x.device)
 probe('randn', lambda: m.draw_noise(B, x.device))
 probe('inv_ex f64', lambda: torch.linalg.inv_ex(torch.eye(6, device='cuda', dtype=torch.float64).expand(2, 6, 6) * 2, check_errors=False))
-probe('cholesky_ex f64', lambda: torch.linalg.cholesky_ex(torch.eye(32, device='cuda', dtype=torch.float64).expand(3, 32, 32) * 2, check_errors=False))
+from vae_gam_amd import ops
+probe('vg cholesky f64', lambda: ops.cholesky((torch.eye(32, device='cuda', dtype=torch.float64).expand(3, 32, 32) * 2).contiguous()))
+probe('solve_triangular f64', lambda: torch.linalg.solve_triangular(torch.eye(32, device='cuda', dtype=torch.float64).expand(3, 32, 32).contiguous(), torch.ones(3, 32, 32, device='cuda', dtype=torch.float64), upper=False))
 probe('gains', lambda: m._gains(cov, noise['eps_beta']))
 probe('encode', lambda: m.encode(x))
 probe('forward_core', lambda: m.forward_core(cov, x, noise))

@@ -347,6 +347,36 @@ def gam_maps(logits, gain, x, eps, glm):
     return maps
 
 
+class CholeskyF64(torch.autograd.Function):
+    """L = chol(A) for a batch of small float64 SPD matrices (vg_cholesky_f64; n <= 128).  Backward is the
+    standard  dA = sym( L^-T  Phi(L^T dL)  L^-1 )  with two triangular solves (rocBLAS trsm, capturable)."""
+
+    @staticmethod
+    def forward(ctx, a):
+        assert a.dtype == torch.float64 and a.dim() == 3 and a.shape[1] == a.shape[2]
+        a = a.contiguous()
+        l = torch.empty_like(a)
+        _call(a, 'vg_cholesky_f64', _p(a), _p(l), a.shape[0], a.shape[1])
+        ctx.save_for_backward(l)
+        return l
+
+    @staticmethod
+    def backward(ctx, gl):
+        (l,) = ctx.saved_tensors
+        p = (l.transpose(1, 2) @ gl).tril()
+        p = p - 0.5 * torch.diag_embed(p.diagonal(dim1=1, dim2=2))
+        x = torch.linalg.solve_triangular(l.transpose(1, 2), p, upper=True)              # L^-T P
+        s = torch.linalg.solve_triangular(l, x, upper=False, left=False)                  # (L^-T P) L^-1
+        return 0.5 * (s + s.transpose(1, 2))
+
+
+def cholesky(a):
+    """Batched lower Cholesky factor; the HIP kernel for float64 n <= 128, torch otherwise."""
+    if a.dtype == torch.float64 and a.shape[-1] <= 128 and (a.is_cuda or _lib.test_library_injected()):
+        return CholeskyF64.apply(a)
+    return torch.linalg.cholesky_ex(a, check_errors=False).L
+
+
 def adam_step_(p, g, m, v, b1, b2, eps, step_scalars):
     """In-place fused Adam over one flat buffer (fp32 or fp64)."""
     lib = _lib.get_lib()

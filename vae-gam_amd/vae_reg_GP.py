@@ -122,6 +122,7 @@ class VAE(nn.Module):
         self.writer = _make_writer(os.path.join(self.save_dir, 'run', ts.strftime('%m_%d_%Y')), tensorboard)
         self.log_maps = False          # per-forward image logging of the reference; opt-in
         self._hrf_cache = {}
+        self._gain_const_cache = {}
         self._glm_f32 = None
         self.use_hip_graph = False     # capture the train step into a hipGraph (bench / long runs)
         self._graphs = {}
@@ -289,6 +290,7 @@ class VAE(nn.Module):
         eye = torch.eye(B, device=dev, dtype=f64)
         beta_cov = (std.pow(2).unsqueeze(1) * xq.pow(2)).unsqueeze(-1) * eye                # :350-351 (diagonal)
         gidx = [i for i, c in enumerate(self.schema) if c.gp]
+        K = self._gain_consts(dev)               # selector tensors built once (host lists would force H2D copies, which a hipGraph capture refuses)
         post = None
         if gidx:
             gn = [names[i] for i in gidx]
@@ -297,22 +299,37 @@ class VAE(nn.Module):
             ls = 3.0 * torch.sigmoid(torch.stack([self.gp_params[n]['log_ls'] for n in gn]).to(f64).exp() + 0.5)  # :357
             qu_m = torch.cat([self.gp_params[n]['qu_m'] for n in gn]).to(f64)
             qu_S = torch.stack([self.gp_params[n]['qu_S'] for n in gn]).to(f64)
-            f_bar, Sigma = gp.posterior_batched(xu, kvar, ls, qu_m, qu_S, xq[gidx])
-            sel = torch.zeros(C, len(gidx), device=dev, dtype=f64)
-            sel[gidx, list(range(len(gidx)))] = 1.0
+            f_bar, Sigma = gp.posterior_batched(xu, kvar, ls, qu_m, qu_S, xq.index_select(0, K['gidx']))
+            sel = K['sel']
             beta_mean = beta_mean + sel @ f_bar                                             # :363
             beta_cov = beta_cov + (sel @ Sigma.reshape(len(gidx), -1)).reshape(C, B, B)     # :364
             gp_kl_loss = gp_kl_loss + gp.kl_batched(qu_m, qu_S).sum()                       # :366-367
             post = (gn, f_bar, Sigma)
-        L = torch.linalg.cholesky_ex(beta_cov + 1e-5 * eye, check_errors=False).L           # :368
+        L = ops.cholesky(beta_cov + 1e-5 * eye)                                             # :368
         task_var = beta_mean + (L @ eps_beta.to(f64).unsqueeze(-1)).squeeze(-1)             # :369
         hidx = [i for i, c in enumerate(self.schema) if c.hrf]
         if hidx:                                                                            # :377-378
             T = self._hrf_matrix(B, dev).to(f64)
             conv = task_var @ T
-            m = torch.zeros(C, 1, device=dev, dtype=f64); m[hidx] = 1.0
+            m = K['hrf_mask']
             task_var = m * conv + (1 - m) * task_var
         return task_var.float(), gp_kl_loss.float(), beta_mean, beta_cov, post
+
+    def _gain_consts(self, dev):
+        key = str(dev)
+        if key not in self._gain_const_cache:
+            C = self.num_covariates
+            gidx = [i for i, c in enumerate(self.schema) if c.gp]
+            hidx = [i for i, c in enumerate(self.schema) if c.hrf]
+            sel = torch.zeros(C, max(len(gidx), 1), dtype=torch.float64)
+            for j, i in enumerate(gidx):
+                sel[i, j] = 1.0
+            m = torch.zeros(C, 1, dtype=torch.float64)
+            for i in hidx:
+                m[i] = 1.0
+            self._gain_const_cache[key] = {'gidx': torch.tensor(gidx, dtype=torch.int64).to(dev), 'sel': sel.to(dev),
+                                           'hrf_mask': m.to(dev)}
+        return self._gain_const_cache[key]
 
     def _glm(self):
         if self._glm_f32 is None or self._glm_f32.device != self.glm_maps.device:
@@ -393,6 +410,9 @@ class VAE(nn.Module):
                 g = self._capture_step(ids, covariates, x)
             if g is not False:
                 g['x'].copy_(x, non_blocking=True); g['cov'].copy_(covariates, non_blocking=True)
+                fresh = self.draw_noise(x.shape[0], x.device)          # same draws, same order as the eager path
+                for k in fresh:
+                    g['noise'][k].copy_(fresh[k])
                 self.optimizer.prepare_step_scalars()
                 g['graph'].replay()
                 return g['loss']
@@ -415,17 +435,26 @@ class VAE(nn.Module):
         import warnings
         key = tuple(x.shape)
         st = {'x': x.clone(), 'cov': covariates.clone(), 'ids': ids.clone()}
+        # parameters / optimiser state are restored after the warm-up + capture passes, so that enabling the
+        # graph does not change the training trajectory (the capture itself executes nothing)
+        snap = [(g, g['p'].clone(), g['m'].clone(), g['v'].clone()) for g in self.optimizer.groups.values()]
+        step0 = self.optimizer.step_count
+        rng = torch.cuda.get_rng_state(x.device)
         try:
+            st['noise'] = self.draw_noise(x.shape[0], x.device)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                       # warm-up on a side stream (allocator, lazy inits)
                 for _ in range(2):
-                    self._train_step_eager(st['ids'], st['cov'], st['x'])
+                    self._train_step_eager(st['ids'], st['cov'], st['x'], noise=st['noise'])
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            self.optimizer.prepare_step_scalars()
             with torch.cuda.graph(graph):
-                st['loss'] = self._train_step_eager(st['ids'], st['cov'], st['x'], advance=False)
+                st['loss'] = self._train_step_eager(st['ids'], st['cov'], st['x'], noise=st['noise'], advance=False)
+            for g, p0, m0, v0 in snap:
+                g['p'].copy_(p0); g['m'].copy_(m0); g['v'].copy_(v0)
+            self.optimizer.step_count = step0
+            torch.cuda.set_rng_state(rng, x.device)
             st['graph'] = graph
             self._graphs[key] = st
         except Exception as e:                                  # noqa: BLE001
