@@ -63,4 +63,28 @@ __device__ __forceinline__ void vg_dma4(const float* gsrc, float* lds_row_base) 
 __device__ __forceinline__ void vg_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
 
+// fp32-input MFMA, exact fp32 (v_mfma_f32_16x16x4_f32): D(16x16) = A(16x4) * B(4x16) + C.
+// lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; it owns D[row = (l>>4)*4 + r][col = l&15], r = 0..3.
+struct vg_f32x4 { float v[4]; };
+#ifdef VG_EMU
+static inline void vg_mfma16(float a, float b, vg_f32x4& acc) {
+    EmuWave& w = g_emu_block->waves[emu_tid / 64]; const int lane = emu_tid % 64;
+    static thread_local int dummy = 0; (void)dummy;
+    w.fbuf[lane] = a; w.bar->arrive_and_wait();
+    float arow[4][4];                                  // A[row][k] for this lane's 4 rows
+    for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k) arow[r][k] = w.fbuf[k * 16 + (lane >> 4) * 4 + r];
+    w.bar->arrive_and_wait();
+    w.fbuf[lane] = b; w.bar->arrive_and_wait();
+    for (int r = 0; r < 4; ++r) { float s = acc.v[r]; for (int k = 0; k < 4; ++k) s = fmaf(arow[r][k], w.fbuf[k * 16 + (lane & 15)], s); acc.v[r] = s; }
+    w.bar->arrive_and_wait();
+}
+#else
+typedef float vg_hw_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void vg_mfma16(float a, float b, vg_f32x4& acc) {
+    vg_hw_f32x4 c = {acc.v[0], acc.v[1], acc.v[2], acc.v[3]};
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    acc.v[0] = c[0]; acc.v[1] = c[1]; acc.v[2] = c[2]; acc.v[3] = c[3];
+}
+#endif
+
 __host__ __device__ static inline int vg_cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -26,6 +26,8 @@ struct WgradParams {
     int b_off;                  // float offset of the b tile inside LDS
 };
 
+__device__ __forceinline__ int clampi_(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
 __device__ __forceinline__ float apply_pro(float v, int relu, float sc, float sh) {
     if (relu) v = fmaxf(v, 0.f);
     return fmaf(v, sc, sh);
@@ -255,6 +257,388 @@ int launch_own(const vg_wgrad_desc* d, const float* a, const float* b, const flo
 }
 
 // ------------------------------------------------------------------------------------------
+// MFMA variant: dw[cb][col] (col = (ca, tap)) as a GEMM  D(16 x 16*NT) += A(16 x 4) * B(4 x 16*NT)
+// over groups of 4 consecutive positions, with the exact-fp32 matrix instruction
+// v_mfma_f32_16x16x4_f32:  A[cb][k] = b[cb][p0+k],  B[k][col] = a[ca][(p0+k)*S + tap - pad].
+// A wave keeps ALL of dw (NT accumulator tiles = 4*NT VGPRs) and walks its share of the positions of
+// the block's LDS tile: per MFMA one ds_read_b32 (the im2col operand, address = position offset +
+// a per-lane column offset computed once) -- no register-level gather, no cross-lane traffic.
+// Blocks are persistent over (sample, position-tile) items; slabs are summed by slab_sum_k.
+// ------------------------------------------------------------------------------------------
+struct WgradMfmaParams {
+    vg_wgrad_desc d;
+    int TPD, TPH, TPWp;         // position tile (TPWp: PW rounded up to a multiple of 4; the tile spans all of W)
+    int tilesH, tilesD;
+    int LD, LH, LW, LWp;        // a-tile geometry per channel
+    int items;
+    int b_off;                  // float offset of the b tile in LDS
+    int red_off;                // float offset of the cross-wave reduction buffer (aliases the tiles)
+};
+
+template <int NT, int KD, int KH, int KW, int S>
+__global__ void __launch_bounds__(256)
+wgrad_mfma_k(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ in_scale,
+             const float* __restrict__ in_shift, float* __restrict__ ws, WgradMfmaParams p) {
+    VG_DYN_SMEM(float, lds);
+    constexpr int KVOL = KD * KH * KW;
+    constexpr int U = 4;
+    const vg_wgrad_desc& d = p.d;
+    const int CA = d.CA, CB = d.CB;
+    const int ncol = CA * KVOL;
+    const int tid = threadIdx.x, lane = tid % VG_WAVE;
+    const int wave = vg_wave_id(), nwaves = blockDim.x / VG_WAVE;
+    float* atile = lds;
+    float* btile = lds + p.b_off;
+
+    // per-lane LDS offset of column (16 t + lane%16) inside the a tile
+    int colOff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = t * 16 + (lane & 15);
+        int off = 0;
+        if (col < ncol) {
+            const int ca = col / KVOL, tap = col % KVOL;
+            const int kd = tap / (KH * KW), kh = (tap / KW) % KH, kw = tap % KW;
+            off = ((ca * p.LD + kd) * p.LH + kh) * p.LWp + kw;
+        }
+        colOff[t] = off;
+    }
+    vg_f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { acc[t].v[0] = 0.f; acc[t].v[1] = 0.f; acc[t].v[2] = 0.f; acc[t].v[3] = 0.f; }
+
+    const int tiles = p.tilesH * p.tilesD;
+    const size_t aplane = (size_t)d.AH * d.AW, bplane = (size_t)d.PH * d.PW;
+    const int rl_a = d.pro_on_a ? d.relu_in : 0, rl_b = d.pro_on_a ? 0 : d.relu_in;
+    for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
+        const int n = item / tiles; const int tile = item % tiles;
+        const int thi = tile % p.tilesH, tdi = tile / p.tilesH;
+        const int pd0 = tdi * p.TPD, ph0 = thi * p.TPH;
+        const int g = (in_scale != nullptr) ? n / d.per_group : 0;
+        __syncthreads();
+        // ---- a tile [CA][LD][LH][LWp]: prologue applied, zero outside the tensor.  U rows of one (c, dz)
+        //      slab per wave and step; the loads are unconditional (clamped addresses) and issued together.
+        {
+            const int ad0 = pd0 * S - d.pad_d, ah0 = ph0 * S - d.pad_h, aw0 = -d.pad_w;
+            for (int c = 0; c < CA; ++c) {
+                float sc = 1.f, sh = 0.f;
+                if (d.pro_on_a && in_scale) { sc = in_scale[g * CA + c]; sh = in_shift[g * CA + c]; }
+                const float* abase = a + ((size_t)n * CA + c) * d.AD * aplane;
+                for (int dz = 0; dz < p.LD; ++dz) {
+                    const int id = ad0 + dz;
+                    const bool dok = id >= 0 && id < d.AD;
+                    const float* pbase = abase + (size_t)clampi_(id, 0, d.AD - 1) * aplane;
+                    float* dplane = atile + (size_t)(c * p.LD + dz) * p.LH * p.LWp;
+                    for (int hy0 = wave * U; hy0 < p.LH; hy0 += nwaves * U) {
+                        for (int wx = lane; wx < p.LW; wx += VG_WAVE) {
+                            const int iw = aw0 + wx;
+                            const bool cok = iw >= 0 && iw < d.AW;
+                            const int iwc = clampi_(iw, 0, d.AW - 1);
+                            float v[U];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) v[u] = pbase[(size_t)clampi_(ah0 + hy0 + u, 0, d.AH - 1) * d.AW + iwc];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                const int hy = hy0 + u, ih = ah0 + hy;
+                                if (hy < p.LH)
+                                    dplane[hy * p.LWp + wx] = (dok && cok && ih >= 0 && ih < d.AH) ? apply_pro(v[u], rl_a, sc, sh) : 0.f;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // ---- b tile [TPD][TPH][TPWp][16] (channel fastest, zero for cb >= CB and outside the tensor)
+        {
+            const int rows = 16 * p.TPD * p.TPH;              // (cb, dz, hy) rows of TPWp positions
+            for (int r = wave; r < rows; r += nwaves) {
+                const int hy = r % p.TPH; const int t = r / p.TPH; const int dz = t % p.TPD; const int c = t / p.TPD;
+                const int pd = pd0 + dz, ph = ph0 + hy;
+                const bool ok = c < CB && pd < d.PD && ph < d.PH;
+                float sc = 1.f, sh = 0.f;
+                if (!d.pro_on_a && in_scale && c < CB) { sc = in_scale[g * CB + c]; sh = in_shift[g * CB + c]; }
+                const float* src = b + (((size_t)n * CB + (ok ? c : 0)) * d.PD + (ok ? pd : 0)) * bplane + (size_t)(ok ? ph : 0) * d.PW;
+                for (int wx = lane; wx < p.TPWp; wx += VG_WAVE) {
+                    const float v = src[min(wx, d.PW - 1)];
+                    btile[((size_t)(dz * p.TPH + hy) * p.TPWp + wx) * 16 + c] = (ok && wx < d.PW) ? apply_pro(v, rl_b, sc, sh) : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- position groups of 4 along w
+        {
+            const int gw = p.TPWp / 4;
+            const int groups = p.TPD * p.TPH * gw;
+            const int k = lane >> 4;
+            for (int gi = wave; gi < groups; gi += nwaves) {
+                const int gx = gi % gw; const int t2 = gi / gw; const int py = t2 % p.TPH; const int pz = t2 / p.TPH;
+                const int px = gx * 4 + k;
+                const float av = btile[((size_t)(pz * p.TPH + py) * p.TPWp + px) * 16 + (lane & 15)];
+                const float* ap = atile + (size_t)(pz * S * p.LH + py * S) * p.LWp + px * S;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) vg_mfma16(av, ap[colOff[t]], acc[t]);
+            }
+        }
+    }
+    // ---- cross-wave reduction through LDS (one wave at a time), then one slab per block
+    float* red = lds + p.red_off;
+    __syncthreads();
+    for (int w = 0; w < nwaves; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int idx = (t * 4 + r) * VG_WAVE + lane;
+                    red[idx] = (w == 0 ? 0.f : red[idx]) + acc[t].v[r];
+                }
+        }
+        __syncthreads();
+    }
+    float* out = ws + (size_t)blockIdx.x * CB * ncol;
+    for (int i = tid; i < NT * 4 * VG_WAVE; i += blockDim.x) {
+        const int l = i % VG_WAVE; const int r = (i / VG_WAVE) % 4; const int t = i / (4 * VG_WAVE);
+        const int cb = (l >> 4) * 4 + r, col = t * 16 + (l & 15);
+        if (cb < CB && col < ncol) out[(size_t)cb * ncol + col] = red[i];
+    }
+}
+
+template <int NT, int KD, int KH, int KW, int S>
+int launch_mfma(const vg_wgrad_desc* d, const float* a, const float* b, const float* in_scale, const float* in_shift,
+                float* ws, float* dw, hipStream_t s, int64_t* ws_bytes_only) {
+    WgradMfmaParams p; p.d = *d;
+    constexpr int KVOL = KD * KH * KW;
+    if (d->CA * KVOL > NT * 16 || d->CB > 16) { vg_set_error("wgrad_mfma: CA=%d CB=%d do not fit NT=%d", d->CA, d->CB, NT); return VG_ERR_UNSUPPORTED; }
+    p.TPWp = (d->PW + 3) & ~3;
+    p.LW = (p.TPWp - 1) * S + KW; p.LWp = p.LW | 1;
+    const size_t budget = 56 * 1024;
+    const size_t red_fl = (size_t)NT * 4 * VG_WAVE;
+    int best_h = 0, best_d = 0;
+    for (int td = 1; td <= 8; ++td)
+        for (int th = 1; th <= 16; ++th) {
+            if (th > d->PH || td > d->PD) continue;
+            const size_t afl = (size_t)d->CA * ((td - 1) * S + KD) * ((th - 1) * S + KH) * p.LWp;
+            const size_t bfl = (size_t)td * th * p.TPWp * 16;
+            if ((afl + bfl + 8) * 4 <= budget && td * th > best_d * best_h) { best_d = td; best_h = th; }
+        }
+    if (best_h == 0) { vg_set_error("wgrad_mfma: tile does not fit LDS"); return VG_ERR_UNSUPPORTED; }
+    p.TPD = best_d; p.TPH = best_h;
+    p.LD = (p.TPD - 1) * S + KD; p.LH = (p.TPH - 1) * S + KH;
+    p.tilesH = vg_cdiv(d->PH, p.TPH); p.tilesD = vg_cdiv(d->PD, p.TPD);
+    p.items = d->N * p.tilesH * p.tilesD;
+    const size_t afl = (size_t)d->CA * p.LD * p.LH * p.LWp;
+    p.b_off = (int)((afl + 3) & ~(size_t)3);
+    const size_t tile_fl = (size_t)p.b_off + (size_t)p.TPD * p.TPH * p.TPWp * 16;
+    p.red_off = 0;
+    const size_t shmem = (tile_fl > red_fl ? tile_fl : red_fl) * sizeof(float) + 64;
+    int grid = p.items < 1024 ? p.items : 1024;
+    const int len = d->CB * d->CA * KVOL;
+    if (ws_bytes_only) { *ws_bytes_only = (int64_t)grid * len * sizeof(float); return VG_OK; }
+    vg_launch(wgrad_mfma_k<NT, KD, KH, KW, S>, dim3(grid), dim3(256), shmem, s, a, b, in_scale, in_shift, ws, p);
+    int rc = vg_check_launch("wgrad_mfma");
+    if (rc) return rc;
+    vg_launch(slab_sum_k, dim3(vg_cdiv(len, 256)), dim3(256), 0, s, (const float*)ws, grid, len, dw);
+    return vg_check_launch("wgrad slab_sum");
+}
+
+// ------------------------------------------------------------------------------------------
+// Plane-staged MFMA variant (pad == 0, every layer of the 41x49x35 network but convt2).
+// Same GEMM as above, but the im2col operand comes from WHOLE input planes of one `a` channel at a time:
+// the LD planes a block of TPD position planes needs are one contiguous span of the tensor, copied flat into
+// LDS by LDS-DMA (double-buffered over the channel loop, which is fully unrolled so that the accumulator
+// tiles of channel ca are named registers), raw; ReLU / batch-norm affine of `a` are applied to the operand
+// on its way from LDS into the MFMA (3 VALU ops beside a 32-cycle matrix instruction).  The b tile
+// ([position][16 channels], prologue applied while staging) is filled once per item by flat coalesced copies.
+// ------------------------------------------------------------------------------------------
+struct WgradPlaneParams {
+    vg_wgrad_desc d;
+    int TPD, TPH, TPWp;         // position planes / rows per b tile; PW rounded up to a multiple of 4
+    int nph;                    // row blocks per plane block (> 1 only when CA == 1)
+    int LD;                     // a planes per item
+    int a_slot;                 // floats per a buffer (LD*AH*AW + slack, multiple of 64)
+    int nbuf;                   // 2: next channel's planes are DMA'd behind the MFMAs; 1: LDS too small for that
+    int b_off;                  // float offset of the b tile
+    int lds_floats;             // total dynamic LDS floats
+    int items, pdblocks;
+};
+
+template <int CA, int TC, int KD, int KH, int KW, int S>
+__global__ void __launch_bounds__(256)
+wgrad_plane_k(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ in_scale,
+              const float* __restrict__ in_shift, float* __restrict__ ws, WgradPlaneParams p) {
+    VG_DYN_SMEM(float, lds);
+    constexpr int KVOL = KD * KH * KW;
+    constexpr int NT = CA * TC;
+    const vg_wgrad_desc& d = p.d;
+    const int CB = d.CB;
+    const int tid = threadIdx.x, lane = tid % VG_WAVE;
+    const int wave = vg_wave_id(), nwaves = blockDim.x / VG_WAVE;
+    float* btile = lds + p.b_off;
+    const int aplane = d.AH * d.AW, bplane = d.PH * d.PW;
+
+    for (int i = tid; i < p.lds_floats; i += blockDim.x) lds[i] = 0.f;       // slack / padding entries stay finite (zero)
+
+    int colOff[TC];                               // offset of tap (16 t + lane%16) inside an a channel, tensor pitches
+#pragma unroll
+    for (int t = 0; t < TC; ++t) {
+        const int tap = t * 16 + (lane & 15);
+        colOff[t] = (tap < KVOL) ? ((tap / (KH * KW)) * d.AH + (tap / KW) % KH) * d.AW + tap % KW : 0;
+    }
+    vg_f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { acc[t].v[0] = 0.f; acc[t].v[1] = 0.f; acc[t].v[2] = 0.f; acc[t].v[3] = 0.f; }
+
+    const int rl_a = d.pro_on_a ? d.relu_in : 0, rl_b = d.pro_on_a ? 0 : d.relu_in;
+    const float lo_a = rl_a ? 0.f : -__builtin_inff();
+    const int gw = p.TPWp / 4;
+    const int groups = p.TPD * p.TPH * gw;
+    const int kq = lane >> 4;
+    __syncthreads();
+    for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
+        const int n = item / p.pdblocks; const int pd0 = (item % p.pdblocks) * p.TPD;
+        const int g = (in_scale != nullptr) ? n / d.per_group : 0;
+        const int ap0 = pd0 * S;                                          // first a plane (pad == 0)
+        const int nfl = max(min(ap0 + p.LD, d.AD) - ap0, 0) * aplane;     // floats per a channel for this item
+        const float* abase = a + (size_t)n * CA * d.AD * aplane + (size_t)ap0 * aplane;
+        __syncthreads();                                                  // previous item's tiles fully consumed
+        // ---- DMA of a channel 0 into buffer 0
+        for (int o = wave * VG_WAVE; o < nfl; o += blockDim.x)
+            if (o + lane < nfl) vg_dma4(abase + o + lane, lds + o);
+        for (int phb = 0; phb < p.nph; ++phb) {
+            const int ph0 = phb * p.TPH;
+            const int nrow = min(p.TPH, d.PH - ph0);                      // valid rows of this block
+            // ---- b tile: rows [ph0, ph0+nrow) of TPD planes, flat coalesced copy per channel -> [position][16]
+            //      (a row-per-wave fill without the index divisions measured 10-60 % slower: rows are 14-33 wide)
+            {
+                const int per_plane = p.TPH * d.PW;
+                const int npos = p.TPD * per_plane;
+                for (int c = 0; c < CB; ++c) {
+                    float sc = 1.f, sh = 0.f;
+                    if (!d.pro_on_a && in_scale) { sc = in_scale[g * CB + c]; sh = in_shift[g * CB + c]; }
+                    const float* src = b + (((size_t)n * CB + c) * d.PD + pd0) * bplane + (size_t)ph0 * d.PW;
+                    for (int f = tid; f < npos; f += blockDim.x) {
+                        const int dz = f / per_plane, r = f % per_plane;
+                        const int py = r / d.PW, pw = r % d.PW;
+                        const bool ok = pd0 + dz < d.PD && py < nrow;
+                        const float v = ok ? apply_pro(src[(size_t)dz * bplane + r], rl_b, sc, sh) : 0.f;
+                        btile[((size_t)(dz * p.TPH + py) * p.TPWp + pw) * 16 + c] = v;
+                    }
+                }
+            }
+            vg_dma_wait();
+            __syncthreads();
+#pragma unroll
+            for (int ca = 0; ca < CA; ++ca) {
+                float* cur = lds + (ca % p.nbuf) * p.a_slot;
+                if (ca + 1 < CA && p.nbuf == 2) {                         // next channel in flight behind this channel's MFMAs
+                    float* nxt = lds + ((ca + 1) & 1) * p.a_slot;
+                    const float* src = abase + (size_t)(ca + 1) * d.AD * aplane;
+                    for (int o = wave * VG_WAVE; o < nfl; o += blockDim.x)
+                        if (o + lane < nfl) vg_dma4(src + o + lane, nxt + o);
+                }
+                float sc = 1.f, sh = 0.f;
+                if (d.pro_on_a && in_scale) { sc = in_scale[g * CA + ca]; sh = in_shift[g * CA + ca]; }
+                for (int gi = wave; gi < groups; gi += nwaves) {
+                    const int gx = gi % gw; const int t2 = gi / gw; const int py = t2 % p.TPH; const int pz = t2 / p.TPH;
+                    const int px = gx * 4 + kq;
+                    const float av = btile[((size_t)(pz * p.TPH + py) * p.TPWp + px) * 16 + (lane & 15)];
+                    const float* ap = cur + (pz * S) * aplane + ((ph0 + py) * S) * d.AW + px * S;
+#pragma unroll
+                    for (int t = 0; t < TC; ++t) {
+                        float bv = ap[colOff[t]];
+                        if (d.pro_on_a) bv = fmaf(fmaxf(bv, lo_a), sc, sh);
+                        vg_mfma16(av, bv, acc[ca * TC + t]);
+                    }
+                }
+                if (CA > 1) {
+                    if (p.nbuf == 2) { vg_dma_wait(); __syncthreads(); }
+                    else if (ca + 1 < CA) {                               // single buffer: refill after everyone is done reading
+                        __syncthreads();
+                        const float* src = abase + (size_t)(ca + 1) * d.AD * aplane;
+                        for (int o = wave * VG_WAVE; o < nfl; o += blockDim.x)
+                            if (o + lane < nfl) vg_dma4(src + o + lane, lds + o);
+                        vg_dma_wait();
+                        __syncthreads();
+                    }
+                }
+            }
+            if (p.nph > 1) __syncthreads();                               // b tile is restaged for the next row block
+        }
+    }
+    // ---- cross-wave reduction through LDS (one wave at a time), then one slab per block
+    float* red = lds;
+    __syncthreads();
+    for (int w = 0; w < nwaves; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int idx = (t * 4 + r) * VG_WAVE + lane;
+                    red[idx] = (w == 0 ? 0.f : red[idx]) + acc[t].v[r];
+                }
+        }
+        __syncthreads();
+    }
+    const int ncol = CA * KVOL;
+    float* out = ws + (size_t)blockIdx.x * CB * ncol;
+    for (int i = tid; i < NT * 4 * VG_WAVE; i += blockDim.x) {
+        const int l = i % VG_WAVE; const int r = (i / VG_WAVE) % 4; const int t = i / (4 * VG_WAVE);
+        const int ca = t / TC, tap = (t % TC) * 16 + (l & 15);
+        const int cb = (l >> 4) * 4 + r;
+        if (cb < CB && tap < KVOL) out[(size_t)cb * ncol + ca * KVOL + tap] = red[i];
+    }
+}
+
+// returns -1 when the geometry does not fit (caller falls back)
+template <int CA, int TC, int KD, int KH, int KW, int S>
+int launch_plane(const vg_wgrad_desc* d, const float* a, const float* b, const float* in_scale, const float* in_shift,
+                 float* ws, float* dw, hipStream_t s, int64_t* ws_bytes_only) {
+    constexpr int KVOL = KD * KH * KW;
+    constexpr int NT = CA * TC;
+    if (d->pad_d || d->pad_h || d->pad_w || d->CA != CA || d->CB > 16) return -1;
+    if ((d->PD - 1) * S + KD > d->AD || (d->PH - 1) * S + KH > d->AH || (d->PW - 1) * S + KW > d->AW) return -1;
+    WgradPlaneParams p; p.d = *d;
+    p.TPWp = (d->PW + 3) & ~3;
+    const int aplane = d->AH * d->AW;
+    const size_t budget = 64 * 1024;
+    const size_t red_fl = (size_t)NT * 4 * VG_WAVE;
+    auto slot_for = [&](int LD) { return (((size_t)LD * aplane + 2 * d->AW + 8 * S + 64 + 63) / 64) * 64; };
+    // preference: whole planes of positions with double-buffered a planes; then single-buffered; then (one `a`
+    // channel only) row blocks of the position plane
+    int best_td = 0, best_th = 0, best_nbuf = 0;
+    for (int nbuf = 2; nbuf >= 1 && !best_td; --nbuf)
+        for (int td = 1; td <= 8 && td <= d->PD; ++td) {
+            const size_t bfl = (size_t)td * d->PH * p.TPWp * 16;
+            if ((nbuf * slot_for((td - 1) * S + KD) + bfl + 64) * 4 <= budget) { best_td = td; best_th = d->PH; best_nbuf = nbuf; }
+        }
+    if (!best_td && CA == 1) {
+        for (int th = d->PH; th >= 1; --th) {
+            const size_t bfl = (size_t)th * p.TPWp * 16;
+            if ((slot_for(KD) + bfl + 64) * 4 <= budget) { best_td = 1; best_th = th; best_nbuf = 1; break; }
+        }
+    }
+    if (!best_td) return -1;
+    p.TPD = best_td; p.TPH = best_th; p.nbuf = best_nbuf; p.nph = vg_cdiv(d->PH, p.TPH);
+    p.LD = (p.TPD - 1) * S + KD;
+    p.a_slot = (int)slot_for(p.LD);
+    p.b_off = p.nbuf * p.a_slot;
+    size_t fl = (size_t)p.b_off + (size_t)p.TPD * p.TPH * p.TPWp * 16 + 64;
+    if (fl < red_fl) fl = red_fl;
+    p.lds_floats = (int)fl;
+    p.pdblocks = vg_cdiv(d->PD, p.TPD);
+    p.items = d->N * p.pdblocks;
+    const int grid = p.items < 768 ? p.items : 768;
+    const int len = d->CB * CA * KVOL;
+    if (ws_bytes_only) { *ws_bytes_only = (int64_t)grid * len * sizeof(float); return VG_OK; }
+    vg_launch(wgrad_plane_k<CA, TC, KD, KH, KW, S>, dim3(grid), dim3(256), fl * sizeof(float), s, a, b, in_scale, in_shift, ws, p);
+    int rc = vg_check_launch("wgrad_plane");
+    if (rc) return rc;
+    vg_launch(slab_sum_k, dim3(vg_cdiv(len, 256)), dim3(256), 0, s, (const float*)ws, grid, len, dw);
+    return vg_check_launch("wgrad slab_sum");
+}
+
+// ------------------------------------------------------------------------------------------
 // wide variant: CB = 8, CA = 1, 3x3x3, stride 1, pad 0  (conv1 and convt5)
 // ------------------------------------------------------------------------------------------
 struct WideParams { vg_wgrad_desc d; int wgroups; long long items; };
@@ -359,9 +743,32 @@ int dispatch(const vg_wgrad_desc* d, const float* a, const float* b, const float
     }
     const bool k333 = d->KD == 3 && d->KH == 3 && d->KW == 3;
     const bool small_w = d->PW <= 8;
+#define PLANE(CA, TC, KD, KH, KW, S) \
+    { int r_ = launch_plane<CA, TC, KD, KH, KW, S>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only); if (r_ >= 0) return r_; }
+    if (d->CB <= 16 && d->PW <= 64) {
+        // (CA == 1, conv1 / convt5: the row-blocked plane variant measured slower than the wide VALU kernel below)
+        if (k333 && d->CA == 8 && d->stride == 1) PLANE(8, 2, 3, 3, 3, 1);
+        if (k333 && d->CA == 8 && d->stride == 2) PLANE(8, 2, 3, 3, 3, 2);
+        if (k333 && d->CA == 16 && d->stride == 1) PLANE(16, 2, 3, 3, 3, 1);
+        if (k333 && d->CA == 16 && d->stride == 2) PLANE(16, 2, 3, 3, 3, 2);
+        if (d->KD == 5 && d->KH == 3 && d->KW == 3 && d->CA == 8 && d->stride == 2) PLANE(8, 3, 5, 3, 3, 2);
+        if (d->KD == 4 && d->KH == 4 && d->KW == 4 && d->CA == 8 && d->stride == 2) PLANE(8, 4, 4, 4, 4, 2);
+    }
+#undef PLANE
     if (d->CB == 8 && d->CA == 1 && k333 && d->stride == 1 && d->pad_d == 0 && d->pad_h == 0 && d->pad_w == 0 &&
         d->AD >= d->PD + 2 && d->AH >= d->PH + 2)
         return launch_wide(d, a, b, in_scale, in_shift, ws, dw, s, ws_only);
+#define MFMA(NT, KD, KH, KW, S) \
+    return launch_mfma<NT, KD, KH, KW, S>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only)
+    if (false && d->CB <= 16 && d->PW <= 64) {
+        if (k333 && d->CA == 8 && d->stride == 1) MFMA(14, 3, 3, 3, 1);
+        if (k333 && d->CA == 8 && d->stride == 2) MFMA(14, 3, 3, 3, 2);
+        if (k333 && d->CA == 16 && d->stride == 1) MFMA(27, 3, 3, 3, 1);
+        if (k333 && d->CA == 16 && d->stride == 2) MFMA(27, 3, 3, 3, 2);
+        if (d->KD == 5 && d->KH == 3 && d->KW == 3 && d->CA == 8 && d->stride == 2) MFMA(23, 5, 3, 3, 2);
+        if (d->KD == 4 && d->KH == 4 && d->KW == 4 && d->CA == 8 && d->stride == 2) MFMA(32, 4, 4, 4, 2);
+    }
+#undef MFMA
 #define OWN(CB, CBT, KD, KH, KW, S, TPW, OKH) \
     return launch_own<CB, CBT, KD, KH, KW, S, TPW, OKH>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only)
     if (k333 && d->CB == 16 && d->CA == 16 && d->stride == 1) { if (small_w) OWN(16, 4, 3, 3, 3, 1, 8, false); OWN(16, 4, 3, 3, 3, 1, 16, false); }
