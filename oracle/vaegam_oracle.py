@@ -91,6 +91,8 @@ def geometry_for(img: Sequence[int], nf: int = 8) -> Geometry:
         # dec 16x20x13 -> 18x22x15 -> (s2, no pad) 37x45x31 -> 39x47x33 -> (k4,s2) 80x96x68 -> 82x98x70
         return Geometry(img, nf, dec_seed=(16, 20, 13), convt2_pad=(0, 0, 0),
                         convt2_outpad=(0, 0, 0), convt4_kernel=(4, 4, 4))
+    if img == (21, 21, 21):      # toy geometry for CPU tests (mirrors vae_gam_amd.schema)
+        return Geometry(img, nf, dec_seed=(1, 1, 1), convt2_pad=(0, 0, 0), convt2_outpad=(0, 0, 0), convt4_kernel=(3, 3, 3))
     raise ValueError('no network geometry defined for image shape %r' % (img,))
 
 

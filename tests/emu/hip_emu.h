@@ -1,20 +1,19 @@
 // hip_emu.h -- TEST HARNESS ONLY.  Minimal host emulation of the HIP execution model so the
-// kernel sources under vae-gam_amd/csrc can be compiled with g++ (-DVG_EMU) and run under
-// AddressSanitizer on tiny shapes.  One OS thread per GPU thread of a block, blocks run one
-// after another; __syncthreads/__shfl are real barriers, so divergent-barrier bugs deadlock
-// here instead of corrupting a GPU.  Never linked into the product library.
+// kernel sources under vae-gam_amd/csrc can be compiled with g++ (-DVG_EMU) and run on tiny shapes.
+// The threads of a block are fibers (ucontext) on one OS thread: __syncthreads / __shfl / MFMA are
+// barriers that switch fibers, so divergent-barrier bugs deadlock here instead of corrupting a GPU;
+// blocks are spread over a few OS threads (`__shared__` is thread_local static, one copy per runner).
+// Never linked into the product library.
 #pragma once
-#include <barrier>
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
-#include <memory>
 #include <mutex>
-#include <thread>
 #include <vector>
-#include <algorithm>
 
 using std::min; using std::max;
 struct float4 { float x, y, z, w; };
@@ -25,38 +24,46 @@ typedef void* hipStream_t;
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
-#define __shared__ static
+#define __shared__ static thread_local
 #define __restrict__ __restrict
 
-struct EmuWave { float fbuf[64]; double dbuf[64]; int lanes; std::unique_ptr<std::barrier<>> bar; };
+struct EmuBar { int count = 0, arrived = 0; unsigned gen = 0; };
+struct EmuWave { float fbuf[64]; double dbuf[64]; int lanes; EmuBar bar; };
 struct EmuBlock {
-    std::unique_ptr<std::barrier<>> bar;
+    EmuBar bar;
     std::vector<EmuWave> waves;
     std::vector<char> dyn;
 };
-extern EmuBlock* g_emu_block;
+extern thread_local EmuBlock* g_emu_block;
 extern thread_local dim3 threadIdx, blockIdx;
-extern dim3 blockDim, gridDim;
+extern thread_local dim3 blockDim, gridDim;
 extern thread_local int emu_tid;
 extern std::mutex g_emu_atomic_mu;
 
+void emu_yield();
+static inline void emu_wait(EmuBar& b) {
+    if (++b.arrived == b.count) { b.arrived = 0; ++b.gen; return; }
+    const unsigned g = b.gen;
+    while (b.gen == g) emu_yield();
+}
+
 #define VG_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(g_emu_block->dyn.data())
 
-static inline void __syncthreads() { g_emu_block->bar->arrive_and_wait(); }
+static inline void __syncthreads() { emu_wait(g_emu_block->bar); }
 static inline float __shfl_down(float v, int d) {
     EmuWave& w = g_emu_block->waves[emu_tid / 64]; int lane = emu_tid % 64;
-    w.fbuf[lane] = v; w.bar->arrive_and_wait();
-    float r = (lane + d < w.lanes) ? w.fbuf[lane + d] : v; w.bar->arrive_and_wait(); return r;
+    w.fbuf[lane] = v; emu_wait(w.bar);
+    float r = (lane + d < w.lanes) ? w.fbuf[lane + d] : v; emu_wait(w.bar); return r;
 }
 static inline double __shfl_down(double v, int d) {
     EmuWave& w = g_emu_block->waves[emu_tid / 64]; int lane = emu_tid % 64;
-    w.dbuf[lane] = v; w.bar->arrive_and_wait();
-    double r = (lane + d < w.lanes) ? w.dbuf[lane + d] : v; w.bar->arrive_and_wait(); return r;
+    w.dbuf[lane] = v; emu_wait(w.bar);
+    double r = (lane + d < w.lanes) ? w.dbuf[lane + d] : v; emu_wait(w.bar); return r;
 }
 static inline float __shfl_xor(float v, int m) {
     EmuWave& w = g_emu_block->waves[emu_tid / 64]; int lane = emu_tid % 64;
-    w.fbuf[lane] = v; w.bar->arrive_and_wait();
-    float r = ((lane ^ m) < w.lanes) ? w.fbuf[lane ^ m] : v; w.bar->arrive_and_wait(); return r;
+    w.fbuf[lane] = v; emu_wait(w.bar);
+    float r = ((lane ^ m) < w.lanes) ? w.fbuf[lane ^ m] : v; emu_wait(w.bar); return r;
 }
 static inline float atomicAdd(float* p, float v) { std::lock_guard<std::mutex> g(g_emu_atomic_mu); float o = *p; *p = o + v; return o; }
 static inline double atomicAdd(double* p, double v) { std::lock_guard<std::mutex> g(g_emu_atomic_mu); double o = *p; *p = o + v; return o; }

@@ -1,0 +1,81 @@
+"""Data-parallel path on CPU: 2 ranks (gloo) each running the PRODUCT model on half of a global minibatch
+through the host build of the kernels == 1 rank on the whole minibatch: batch-norm statistics are
+all-reduced per layer, the gains are evaluated on the all-gathered covariates with identical noise, the flat
+gradient buffers are summed once.  Also the sharded iteration order of DeviceResidentData."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import toy_case as T
+from vae_gam_amd import _lib
+
+# 8 volumes: the toy decoder seed is 1x1x1, so its first batch-norm sees only B values per statistic; at B=4 the
+# variance of 4 numbers is so ill-conditioned that a different fp32 summation order (2+2 vs 4) moves gradients by 5e-3
+B_GLOBAL, C = 8, 3
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _single_process_reference():
+    T.load_emu_library()
+    x, cov, xu, glm = T.make_inputs(B_GLOBAL, C, seed=11)
+    model = T.make_model(C, xu, glm)
+    gen = torch.Generator().manual_seed(1234)
+    noise = {'eps_w': torch.randn(B_GLOBAL, 1, generator=gen), 'eps_d': torch.randn(B_GLOBAL, 32, generator=gen),
+             'eps_beta': torch.randn(C, B_GLOBAL, generator=gen)}
+    loss = model.train_step(torch.zeros(B_GLOBAL, dtype=torch.int64), cov, x, noise=noise)
+    g32 = model.optimizer.groups[torch.float32]
+    return float(loss), g32['g'].clone(), g32['p'].clone(), model.epsilon.detach().clone()
+
+
+def _rank_main(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from vae_gam_amd import dp as dpmod
+    T.load_emu_library()
+    ctx = dpmod.DataParallelContext.from_env(backend='gloo')
+    x, cov, xu, glm = T.make_inputs(B_GLOBAL, C, seed=11)
+    model = T.make_model(C, xu, glm, dp=ctx)
+    b = B_GLOBAL // world
+    sl = slice(rank * b, (rank + 1) * b)
+    loss = model.train_step(torch.zeros(b, dtype=torch.int64), cov[sl], x[sl])          # noise: the shared seeded generator
+    g32 = model.optimizer.groups[torch.float32]
+    torch.save({'loss': float(loss), 'g': g32['g'].clone(), 'p': g32['p'].clone(), 'eps': model.epsilon.detach().clone()},
+               os.path.join(out_dir, 'rank%d.pt' % rank))
+    ctx.shutdown()
+
+
+def test_two_ranks_equal_one_rank_global_batch(tmp_path):
+    ref_loss, ref_g, ref_p, ref_eps = _single_process_reference()
+    port = _free_port()
+    mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [torch.load(os.path.join(tmp_path, 'rank%d.pt' % r)) for r in range(2)]
+    for o in outs:
+        np.testing.assert_allclose(o['loss'], ref_loss, rtol=2e-5)
+        gn = float(ref_g.norm())
+        assert float((o['g'] - ref_g).norm()) <= 2e-4 * gn, (float((o['g'] - ref_g).norm()), gn)     # fp32 reduction order only
+        np.testing.assert_allclose(o['eps'].numpy(), ref_eps.numpy(), atol=1e-9)
+    assert torch.equal(outs[0]['p'], outs[1]['p'])                  # replicas stay identical
+    moved = (ref_p - outs[0]['p']).abs()
+    assert float(moved.max()) <= 2.1e-3                             # differences only where a near-zero gradient changed sign
+
+
+def test_device_resident_data_shards_every_global_batch():
+    from vae_gam_amd.DataClass_GP import DeviceResidentData
+    N = 20
+    vols = torch.arange(N, dtype=torch.float32).view(N, 1, 1, 1).expand(N, 2, 2, 2).contiguous()
+    cov = torch.arange(N, dtype=torch.float32).view(N, 1).repeat(1, 3)
+    sid = torch.zeros(N, dtype=torch.int64)
+    full = [b['covariates'][:, 0].tolist() for b in DeviceResidentData(vols, cov, sid, batch_size=8, shuffle=True, seed=3)]
+    parts = [[b['covariates'][:, 0].tolist() for b in DeviceResidentData(vols, cov, sid, batch_size=8, shuffle=True, seed=3, rank=r, world=2)]
+             for r in range(2)]
+    assert len(full) == 2 and all(len(b) == 8 for b in full)
+    for i, batch in enumerate(full):
+        assert parts[0][i] + parts[1][i] == batch

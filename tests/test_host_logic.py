@@ -1,0 +1,152 @@
+"""Host-side surface of the drop-in (no GPU): covariate schema, seeded construction, checkpoint dictionary,
+optimizer state format, CLI flags, data classes, synthetic generator, HRF kernel."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import vae_gam_amd  # noqa: F401
+from vae_gam_amd import DataClass_GP, multsubj_reg_run_GP, schema, synthetic, utils
+from vae_gam_amd.vae_reg_GP import VAE
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def small_ds():
+    return synthetic.make_dataset(num_subjects=2, vols_per_subject=6, num_covariates=8, seed=1)
+
+
+def test_schema_reduces_to_reference_rules():
+    s8 = schema.covariate_schema(8)
+    assert [c.name for c in s8] == ['task', 'x', 'y', 'z', 'xrot', 'yrot', 'zrot', 'sex']
+    assert [c.gp for c in s8] == [False, True, True, True, True, True, True, False]          # 1 < i < 8
+    assert [c.hrf for c in s8] == [True] + [False] * 7                                        # i < C-6
+    assert [c.hrf for c in schema.covariate_schema(8, neural_covariates=False)] == [False] * 8
+    s3 = schema.covariate_schema(3)
+    assert [c.name for c in s3] == ['task', 'x', 'y'] and not any(c.hrf for c in s3)
+    s12 = schema.covariate_schema(12)
+    assert len(s12) == 12 and s12[0].name == 'task' and s12[-1].name == 'sex' and sum(c.gp for c in s12) == 10
+    g = schema.net_geometry((41, 49, 35))
+    assert g.enc_flat == 3072 and g.dec_flat == 3840 and g.dec_sizes()[-1] == (41, 49, 35)   # vae_reg_GP.py:197,210
+    assert schema.net_geometry((82, 98, 70)).dec_sizes()[-1] == (82, 98, 70)
+
+
+def test_hrf_kernel_values():
+    h = utils.hrf(np.arange(0, 20, 1.4))
+    ref = [0, .040384, .318517, .593309, .6, .408907, .180511, .010367, -.079018, -.104684, -.094269, -.070497,
+           -.046685, -.028236, -.015885]
+    np.testing.assert_allclose(h, ref, atol=1e-6)
+
+
+def test_seeded_model_matches_reference_parameter_order_and_checkpoint(small_ds, tmp_path):
+    meta = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'ref_B4_C8.json')))
+    torch.manual_seed(1)
+    m = VAE(num_covariates=8, glm_maps=small_ds['glm'], xu_ranges=small_ds['xu_ranges'], device_name='cpu', save_dir=str(tmp_path))
+    assert [n for n, _ in m.named_parameters()] == meta['param_order']
+    assert sum(p.numel() for p in m.parameters()) == 1564424
+    assert m.epsilon.dtype == torch.float64 and m.glm_maps.dtype == torch.float64
+    m.epoch = 7
+    m.save_state('ck.tar')
+    ck = torch.load(os.path.join(tmp_path, 'ck.tar'), weights_only=False)
+    ref = meta['checkpoint_keys']
+    assert set(ck.keys()) == set(ref.keys())
+    for layer in ('conv1', 'convt5', 'bn1', 'fc8'):
+        assert sorted(ck[layer].keys()) == ref[layer]
+    assert {k: sorted(v.keys()) for k, v in ck['gp_params'].items()} == ref['gp_params']
+    assert sorted(ck['optimizer_state']['param_groups'][0].keys()) == ref['optimizer_state']['param_groups_keys']
+    assert len(ck['optimizer_state']['param_groups'][0]['params']) == 97
+    # round trip into a differently seeded model: values are copied INTO the live parameters
+    torch.manual_seed(5)
+    m2 = VAE(num_covariates=8, glm_maps=small_ds['glm'], xu_ranges=small_ds['xu_ranges'], device_name='cpu', save_dir=str(tmp_path))
+    ids_before = {n: p.data_ptr() for n, p in m2.named_parameters()}
+    m2.load_state(os.path.join(tmp_path, 'ck.tar'))
+    assert m2.epoch == 7
+    for (n, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p, q), n
+        assert q.data_ptr() == ids_before[n]                 # still the tensors the optimiser updates
+    assert m2.gp_params['x']['qu_S'] is m2.qu_S_x
+
+
+def test_checkpoint_loads_into_torch_adam(small_ds, tmp_path):
+    """optimizer_state is torch.optim.Adam's own format: the reference's load_state can consume it."""
+    torch.manual_seed(1)
+    m = VAE(num_covariates=8, glm_maps=small_ds['glm'], xu_ranges=small_ds['xu_ranges'], device_name='cpu', save_dir=str(tmp_path))
+    m.optimizer.step_count = 3
+    g = m.optimizer.groups[torch.float32]; g['m'].normal_(); g['v'].uniform_()
+    sd = m.optimizer.state_dict()
+    ref_opt = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in m.parameters()], lr=1e-3)
+    ref_opt.load_state_dict(sd)
+    st = ref_opt.state_dict()['state']
+    assert len(st) == 97 and float(st[0]['step']) == 3.0
+    m.optimizer.load_state_dict(ref_opt.state_dict())
+    assert m.optimizer.step_count == 3
+
+
+def test_forward_without_gpu_raises(small_ds):
+    torch.manual_seed(1)
+    m = VAE(num_covariates=8, glm_maps=small_ds['glm'], xu_ranges=small_ds['xu_ranges'], device_name='cpu')
+    x = torch.from_numpy(small_ds['volumes'][:2]); cov = torch.from_numpy(small_ds['covariates'][:2])
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        m.forward(torch.zeros(2, dtype=torch.int64), cov, x, 'train', train_mode=False)
+
+
+def test_cli_flags_match_reference():
+    a = multsubj_reg_run_GP.build_parser().parse_args([])
+    assert (a.batch_size, a.epochs, a.seed, a.save_freq, a.test_freq, a.split) == (32, 300, 1, 100, 200, 98)
+    assert (a.glm_reg_scale, a.num_inducing_pts, a.gp_kl_scale) == (1.0, 6, 10.0)
+    assert a.from_ckpt is False and a.recons_only is False and a.neural_covariates is True
+    b = multsubj_reg_run_GP.build_parser().parse_args(['--from_ckpt', '--neural_covariates', 'no', '--batch-size', '64'])
+    assert b.from_ckpt is True and b.neural_covariates is False and b.batch_size == 64
+
+
+def test_dataset_sample_dictionary_and_loaders(small_ds, tmp_path):
+    csv, glm_csv = synthetic.write_csvs(small_ds, str(tmp_path))
+    ds = DataClass_GP.FMRIDataset(csv, transform=DataClass_GP.ToTensor())
+    assert len(ds) == 12
+    s = ds[7]
+    assert set(s.keys()) == {'covariates', 'volume', 'subjid', 'vol_num'}
+    assert s['covariates'].shape == (8,) and s['covariates'].dtype == torch.float32
+    assert s['volume'].shape == (41, 49, 35) and s['volume'].dtype == torch.float32
+    assert s['subjid'].dtype == torch.int64 and int(s['subjid']) == 1 and s['vol_num'].dtype == torch.float64
+    np.testing.assert_allclose(s['volume'].numpy(), small_ds['volumes'][7], atol=1e-6)       # /3284.5 undone exactly
+    np.testing.assert_allclose(s['covariates'].numpy(), small_ds['covariates'][7], atol=1e-6)
+    loaders = DataClass_GP.setup_data_loaders(batch_size=4, train_csv=csv, test_csv=csv)
+    assert set(loaders) == {'Shuffled_train', 'UnShuffled_train', 'test'}
+    b = next(iter(loaders['UnShuffled_train']))
+    assert b['volume'].shape == (4, 41, 49, 35) and b['covariates'].shape == (4, 8)
+    assert utils.get_xu_ranges([csv, csv])[0][0] == pytest.approx(small_ds['xu_ranges'][0][0], abs=1e-5)
+    glm = np.loadtxt(glm_csv, delimiter=',', skiprows=1)
+    assert glm.shape == (70315, 9)
+
+
+def test_nifti1_reader(tmp_path):
+    import struct
+    a = np.arange(2 * 3 * 4 * 5, dtype=np.int16).reshape((2, 3, 4, 5), order='F')
+    hdr = bytearray(352)
+    struct.pack_into('<i', hdr, 0, 348)
+    struct.pack_into('<8h', hdr, 40, 4, 2, 3, 4, 5, 1, 1, 1)
+    struct.pack_into('<2h', hdr, 70, 4, 16)
+    struct.pack_into('<f', hdr, 108, 352.0)
+    struct.pack_into('<2f', hdr, 112, 2.0, 1.0)
+    path = str(tmp_path / 't.nii')
+    open(path, 'wb').write(bytes(hdr) + a.tobytes(order='F'))
+    out = DataClass_GP.read_nifti1(path)
+    np.testing.assert_allclose(out, a * 2.0 + 1.0)
+
+
+def test_synthetic_set_is_seeded_and_has_the_control_signal():
+    a = synthetic.make_dataset(num_subjects=1, vols_per_subject=30, num_covariates=3, seed=4)
+    b = synthetic.make_dataset(num_subjects=1, vols_per_subject=30, num_covariates=3, seed=4)
+    assert np.array_equal(a['volumes'], b['volumes']) and np.array_equal(a['covariates'], b['covariates'])
+    assert a['volumes'].min() >= 0 and a['volumes'].max() <= 1
+    task = a['covariates'][:, 0]
+    assert task[0] == 1 and task[14] == 0                       # ON first, 20 s blocks at TR 1.4 (utils.py:93-111)
+    sig = synthetic.large3_signal()
+    inside = np.zeros_like(sig, dtype=bool); inside[15:25, 34:47, 9:22] = True
+    assert sig[inside].sum() > 0 and not sig[~inside].any()
+    on = a['volumes'][task == 1].mean(0); off = a['volumes'][task == 0].mean(0)
+    assert (on - off)[sig > 0].mean() > 0.2                      # the glyph is there when the block is ON
+    assert a['covariates'][:, 1].min() < -3 and a['covariates'][:, 1].max() > 3   # wide range keeps Ku conditioned (H2)

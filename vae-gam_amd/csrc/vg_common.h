@@ -69,14 +69,13 @@ struct vg_f32x4 { float v[4]; };
 #ifdef VG_EMU
 static inline void vg_mfma16(float a, float b, vg_f32x4& acc) {
     EmuWave& w = g_emu_block->waves[emu_tid / 64]; const int lane = emu_tid % 64;
-    static thread_local int dummy = 0; (void)dummy;
-    w.fbuf[lane] = a; w.bar->arrive_and_wait();
+    w.fbuf[lane] = a; emu_wait(w.bar);
     float arow[4][4];                                  // A[row][k] for this lane's 4 rows
     for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k) arow[r][k] = w.fbuf[k * 16 + (lane >> 4) * 4 + r];
-    w.bar->arrive_and_wait();
-    w.fbuf[lane] = b; w.bar->arrive_and_wait();
+    emu_wait(w.bar);
+    w.fbuf[lane] = b; emu_wait(w.bar);
     for (int r = 0; r < 4; ++r) { float s = acc.v[r]; for (int k = 0; k < 4; ++k) s = fmaf(arow[r][k], w.fbuf[k * 16 + (lane & 15)], s); acc.v[r] = s; }
-    w.bar->arrive_and_wait();
+    emu_wait(w.bar);
 }
 #else
 typedef float vg_hw_f32x4 __attribute__((ext_vector_type(4)));

@@ -18,9 +18,23 @@ import torch.distributed as dist
 
 
 class DataParallelContext:
-    def __init__(self, rank, world_size, device, group=None):
+    def __init__(self, rank, world_size, device, group=None, noise_seed=1234):
         self.rank, self.world_size, self.device, self.group = rank, world_size, device, group
         self.bn_sync = _BnSync(self)
+        self.noise_seed = noise_seed
+        self._gens = {}
+        # gloo cannot reduce device tensors in every build: stage through the host then (tests on one GPU)
+        self._host_staging = dist.get_backend(group) == 'gloo' and device.type == 'cuda'
+        t = torch.zeros(1, device=device)
+        self.allreduce_sum_(t)                               # creates the communicator outside any graph capture
+
+    def noise_generator(self, device):
+        key = str(device)
+        if key not in self._gens:
+            g = torch.Generator(device=device)
+            g.manual_seed(self.noise_seed)
+            self._gens[key] = g
+        return self._gens[key]
 
     @classmethod
     def from_env(cls, backend=None):
@@ -40,33 +54,39 @@ class DataParallelContext:
 
     # ---- collectives
     def allreduce_sum_(self, t):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        if self._host_staging and t.is_cuda:
+            h = t.cpu(); dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group); t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def allreduce_grads(self, flat_grads):
         """Sum the flat gradient buffers over ranks (loss terms are pre-scaled so that the SUM is the
-        global-batch gradient)."""
+        global-batch gradient): one collective per dtype buffer (fp32 parameters, fp64 epsilon map)."""
         for g in flat_grads:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            self.allreduce_sum_(g)
 
     def all_gather_rows(self, t):
         """(b, ...) per rank -> (world*b, ...) in rank order."""
-        out = torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
-        return out
+        t = t.contiguous()
+        if self._host_staging and t.is_cuda:
+            parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(self.world_size)]
+            dist.all_gather(parts, t.cpu(), group=self.group)
+            return torch.cat(parts, 0).to(t.device)
+        parts = [torch.empty_like(t) for _ in range(self.world_size)]
+        dist.all_gather(parts, t, group=self.group)
+        return torch.cat(parts, 0)
 
     def barrier(self):
         dist.barrier(group=self.group)
 
     def max_scalar(self, v):
-        t = torch.tensor([float(v)], dtype=torch.float64, device=self.device)
+        t = torch.tensor([float(v)], dtype=torch.float64, device='cpu' if self._host_staging else self.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
 
     def sum_scalar_tensor(self, t):
-        t = t.clone()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return t
+        return self.allreduce_sum_(t.clone())
 
     def shard_loaders(self, loaders, global_batch, seed):
         return loaders            # file-backed loaders: every rank reads its own per-rank batch (see CLI)

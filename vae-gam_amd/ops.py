@@ -210,12 +210,17 @@ def bn_backward_(dxe, p, gamma, mean, rstd, relu, per_group, sync=None):
     _call(p, 'vg_bn_bwd_reduce', _p(_chk(dxe)), _p(_chk(p)), N, C, P, per_group, int(relu), _p(mean), _p(rstd), _p(ws),
              _p(sums))
     count = float(per_group * P)
+    local = None
     if sync is not None:
+        local = sums.clone()                       # this rank's share of dgamma / dbeta (the gradient all-reduce sums them)
         sums = sync(sums)
         count = count * sync.world_size
     parts = torch.empty((2, G, C), dtype=torch.float32, device=p.device)
     _call(p, 'vg_bn_bwd_apply', _p(dxe), _p(p), N, C, P, per_group, int(relu), _p(gamma), _p(mean), _p(rstd), _p(sums),
              count, _p(parts[0]), _p(parts[1]))
+    if local is not None:
+        loc = local.view(G, C, 2).sum(0).float()
+        return loc[:, 1].contiguous(), loc[:, 0].contiguous()
     return parts[0].sum(0), parts[1].sum(0)
 
 

@@ -266,9 +266,13 @@ class VAE(nn.Module):
         return (covariate_vals.unsqueeze(0) @ self._hrf_matrix(B, covariate_vals.device)).squeeze(0)
 
     def draw_noise(self, B, device):
-        """The reference's draws per forward, in its order: (B,1), (B,L), then C x (B,)  (SURVEY 4)."""
-        return {'eps_w': torch.randn(B, 1, device=device), 'eps_d': torch.randn(B, self.num_latents, device=device),
-                'eps_beta': torch.randn(self.num_covariates, B, device=device)}
+        """The reference's draws per forward, in its order: (B,1), (B,L), then C x (B,)  (SURVEY 4).
+        Data-parallel: B is the GLOBAL batch and the draws come from a generator seeded identically on every
+        rank, so all ranks hold the same noise and each uses its slice."""
+        gen = None if self.dp is None else self.dp.noise_generator(device)
+        return {'eps_w': torch.randn(B, 1, device=device, generator=gen),
+                'eps_d': torch.randn(B, self.num_latents, device=device, generator=gen),
+                'eps_beta': torch.randn(self.num_covariates, B, device=device, generator=gen)}
 
     def _gains(self, covariates, eps_beta):
         """All C gains of a minibatch at once (vae_reg_GP.py:345-378).
@@ -346,12 +350,18 @@ class VAE(nn.Module):
         dev = x.device
         x = x.float()
         covariates = covariates.float()
+        # data parallel: this rank holds rows [lo, lo+B) of a global batch of Bg = world*B volumes
+        W, lo, Bg = 1, 0, B
+        if self.dp is not None:
+            W = self.dp.world_size; lo = self.dp.rank * B; Bg = W * B
+            covariates = self.dp.all_gather_rows(covariates)                                # (Bg, C): the gains couple the batch
         if noise is None:
-            noise = self.draw_noise(B, dev)
+            noise = self.draw_noise(Bg, dev)
+        eps_w, eps_d = noise['eps_w'][lo:lo + B], noise['eps_d'][lo:lo + B]
         mu, u, d = self.encode(x)
         d = d + 1e-6 * (d < 1e-6).any().to(d.dtype)                                        # :321-323 without the sync
         w = u.squeeze(-1)
-        z = mu + w * noise['eps_w'] + d.sqrt() * noise['eps_d']                             # rsample, :325
+        z = mu + w * eps_w + d.sqrt() * eps_d                                               # rsample, :325
         cap = 1.0 + (w * w / d).sum(-1)
         kl_z = 0.5 * (-(cap.log() + d.log().sum(-1)) + d.sum(-1) + (w * w).sum(-1) + (mu * mu).sum(-1) - L)   # :400
         G = C + 1
@@ -359,11 +369,14 @@ class VAE(nn.Module):
         zcat = torch.cat([z.unsqueeze(0).expand(G, B, L), oh], 2).reshape(G * B, L + G)     # :326-329, 339-342
         logits = self._decode_logits(zcat, B).view(G, B, self.img_dim)
         task_var, gp_kl_loss, beta_mean, beta_cov, post = self._gains(covariates, noise['eps_beta'])
+        if W > 1:
+            task_var = task_var[:, lo:lo + B].contiguous()                                  # full-batch gains, this rank's columns
         xf = x.reshape(B, self.img_dim)
         slp, dist = ops.GamElbo.apply(logits, task_var, xf, self.epsilon.view(-1), self._glm())
-        glm_reg = B * dist.sum()                                                            # :388-389
-        elbo = (-kl_z + slp).mean(0)                                                        # :406-408
-        loss = -elbo + self.gp_kl_scale * gp_kl_loss + self.glm_reg_scale * glm_reg         # :410
+        glm_reg = Bg * dist.sum()                                                           # :388-389 (cdist's factor = global batch)
+        elbo = (-kl_z + slp).sum(0) / Bg                                                    # :406-408 (mean over the global batch)
+        # replicated terms are divided by the world size: the gradient all-reduce SUMS the per-rank losses
+        loss = -elbo + self.gp_kl_scale * gp_kl_loss / W + self.glm_reg_scale * glm_reg     # :410
         out = dict(loss=loss, z=z, mu=mu, u=u, d=d, kl_z=kl_z, task_var=task_var, gp_kl_loss=gp_kl_loss,
                    glm_reg=glm_reg, sum_log_prob=slp, dist=dist, logits=logits, beta_mean=beta_mean, beta_cov=beta_cov,
                    gp_post=post)
@@ -410,7 +423,8 @@ class VAE(nn.Module):
                 g = self._capture_step(ids, covariates, x)
             if g is not False:
                 g['x'].copy_(x, non_blocking=True); g['cov'].copy_(covariates, non_blocking=True)
-                fresh = self.draw_noise(x.shape[0], x.device)          # same draws, same order as the eager path
+                Bg = x.shape[0] * (1 if self.dp is None else self.dp.world_size)
+                fresh = self.draw_noise(Bg, x.device)                   # same draws, same order as the eager path
                 for k in fresh:
                     g['noise'][k].copy_(fresh[k])
                 self.optimizer.prepare_step_scalars()
@@ -427,7 +441,10 @@ class VAE(nn.Module):
         if advance:
             self.optimizer.prepare_step_scalars()
         self.optimizer.apply_update()
-        return loss.detach()
+        loss = loss.detach()
+        if self.dp is not None:
+            loss = self.dp.sum_scalar_tensor(loss)               # per-rank partials -> the global-batch loss
+        return loss
 
     def _capture_step(self, ids, covariates, x):
         """Capture the train step for this batch shape; falls back to eager launches (and says so) if an
@@ -441,7 +458,7 @@ class VAE(nn.Module):
         step0 = self.optimizer.step_count
         rng = torch.cuda.get_rng_state(x.device)
         try:
-            st['noise'] = self.draw_noise(x.shape[0], x.device)
+            st['noise'] = self.draw_noise(x.shape[0] * (1 if self.dp is None else self.dp.world_size), x.device)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                       # warm-up on a side stream (allocator, lazy inits)
