@@ -52,6 +52,13 @@ def _rank_main(rank, world, port, out_dir):
     ctx.shutdown()
 
 
+@pytest.fixture(autouse=True)
+def restore_library():
+    prev = _lib._LIB
+    yield
+    _lib.set_library_for_tests(prev)
+
+
 def test_two_ranks_equal_one_rank_global_batch(tmp_path):
     ref_loss, ref_g, ref_p, ref_eps = _single_process_reference()
     port = _free_port()

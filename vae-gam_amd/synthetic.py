@@ -59,9 +59,9 @@ def make_dataset(num_subjects=2, vols_per_subject=98, num_covariates=8, img_shap
             v = base + sig * task[t] + 0.01 * rng.standard_normal((X, Y, Z))
             vols[s * T + t] = np.clip(v, 0.0, 1.0)
     ncont = 6 if C <= 8 else C - 2
-    cont = rng.standard_normal((N, ncont))
-    cont[0] += 6.0; cont[1] -= 4.0                              # two outliers per column keep Ku well conditioned
-    cont = utils.zscore_columns(cont)
+    cont = utils.zscore_columns(rng.standard_normal((N, ncont)))
+    cont[0] = 6.0 + 0.1 * rng.standard_normal(ncont)            # two outliers per column: every covariate spans ~[-4, 6],
+    cont[1] = -4.0 + 0.1 * rng.standard_normal(ncont)           # which keeps the inducing-point kernel Ku well conditioned
     sex = np.repeat((np.arange(S) % 2).astype(np.float64), T)
     full = np.concatenate([np.tile(task, S)[:, None], cont, sex[:, None]], 1)
     covariates = full[:, :C] if C <= 8 else full
