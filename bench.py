@@ -96,6 +96,7 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: no GPU visible (the hot path has no CPU fallback)')
+    local_rank = local_rank % torch.cuda.device_count()        # (tests: several ranks may share one GPU over gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     _lib.get_lib()
@@ -123,7 +124,9 @@ def main():
         if dp is not None:
             dp.barrier()
 
-    model.use_hip_graph = not a.eager
+    # N > 1: the RCCL collectives inside a captured graph could not be exercised on the one-GPU development box,
+    # so multi-GPU runs launch eagerly unless VG_DP_GRAPH=1 asks for the capture (which falls back to eager on error)
+    model.use_hip_graph = (not a.eager) and (world == 1 or os.environ.get('VG_DP_GRAPH') == '1')
     run_steps(a.warmup)
     graphed = bool(model._graphs) and all(v is not False for v in model._graphs.values())
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()

@@ -167,3 +167,42 @@ def test_forward_requires_gpu_tensors():
     with pytest.raises(RuntimeError, match='no CPU path'):
         model.forward(torch.zeros(2, dtype=torch.int64), torch.from_numpy(ds['covariates'][:2]),
                       torch.from_numpy(ds['volumes'][:2]), 'train', train_mode=False)
+
+
+def _dp_rank(rank, world, port, out_dir):
+    import os
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    from vae_gam_amd import dp as dpmod, synthetic
+    ctx = dpmod.DataParallelContext.from_env(backend='gloo')          # one GPU on this box: collectives staged through the host
+    ds = synthetic.make_dataset(num_subjects=1, vols_per_subject=16, num_covariates=3, seed=6)
+    torch.manual_seed(1)
+    model = VAE(num_covariates=3, glm_maps=ds['glm'], xu_ranges=ds['xu_ranges'], device_name='cuda', data_parallel=ctx)
+    Bg = 8; b = Bg // world
+    x = torch.from_numpy(ds['volumes'][rank * b:(rank + 1) * b]).cuda(); cov = torch.from_numpy(ds['covariates'][rank * b:(rank + 1) * b]).cuda()
+    loss = model.train_step(torch.zeros(b, dtype=torch.int64, device='cuda'), cov, x)
+    g32 = model.optimizer.groups[torch.float32]
+    torch.save({'loss': float(loss), 'g': g32['g'].cpu(), 'p': g32['p'].cpu()}, os.path.join(out_dir, 'rank%d.pt' % rank))
+    ctx.shutdown()
+
+
+def test_data_parallel_two_ranks_on_gpu_equal_global_batch(tmp_path):
+    """2 ranks (both on this box's single GPU, gloo) x 4 volumes == 1 rank x 8 volumes on the HIP path."""
+    import socket
+    import torch.multiprocessing as mp
+    from vae_gam_amd import synthetic
+    ds = synthetic.make_dataset(num_subjects=1, vols_per_subject=16, num_covariates=3, seed=6)
+    torch.manual_seed(1)
+    model = VAE(num_covariates=3, glm_maps=ds['glm'], xu_ranges=ds['xu_ranges'], device_name='cuda')
+    gen = torch.Generator(device='cuda'); gen.manual_seed(1234)
+    noise = {'eps_w': torch.randn(8, 1, device='cuda', generator=gen), 'eps_d': torch.randn(8, 32, device='cuda', generator=gen),
+             'eps_beta': torch.randn(3, 8, device='cuda', generator=gen)}
+    x = torch.from_numpy(ds['volumes'][:8]).cuda(); cov = torch.from_numpy(ds['covariates'][:8]).cuda()
+    ref_loss = float(model.train_step(torch.zeros(8, dtype=torch.int64, device='cuda'), cov, x, noise=noise))
+    ref_g = model.optimizer.groups[torch.float32]['g'].cpu()
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_dp_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        o = torch.load(os.path.join(tmp_path, 'rank%d.pt' % r))
+        np.testing.assert_allclose(o['loss'], ref_loss, rtol=2e-5)
+        assert float((o['g'] - ref_g).norm()) <= 5e-4 * float(ref_g.norm()), (float((o['g'] - ref_g).norm()), float(ref_g.norm()))

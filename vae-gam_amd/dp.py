@@ -42,15 +42,19 @@ class DataParallelContext:
         local = int(os.environ.get('LOCAL_RANK', '0'))
         cuda = torch.cuda.is_available()
         if backend is None:
-            backend = 'nccl' if cuda else 'gloo'
+            backend = os.environ.get('VG_DP_BACKEND') or ('nccl' if cuda else 'gloo')     # nccl = RCCL over xGMI
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if not dist.is_initialized():
             if cuda:
+                local = local % max(torch.cuda.device_count(), 1)
                 torch.cuda.set_device(local)
-                dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device('cuda', local))
+                if backend == 'nccl':
+                    dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device('cuda', local))
+                else:
+                    dist.init_process_group(backend, rank=rank, world_size=world)
             else:
                 dist.init_process_group(backend, rank=rank, world_size=world)
-        return cls(rank, world, torch.device('cuda', local) if cuda else torch.device('cpu'))
+        return cls(rank, world, torch.device('cuda', local % max(torch.cuda.device_count(), 1)) if cuda else torch.device('cpu'))
 
     # ---- collectives
     def allreduce_sum_(self, t):

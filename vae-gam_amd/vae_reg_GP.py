@@ -478,6 +478,10 @@ class VAE(nn.Module):
             warnings.warn('hipGraph capture of the train step failed (%s: %s); running eager launches' % (type(e).__name__, e))
             self._graphs[key] = False
             torch.cuda.synchronize()
+            for g, p0, m0, v0 in snap:
+                g['p'].copy_(p0); g['m'].copy_(m0); g['v'].copy_(v0)
+            self.optimizer.step_count = step0
+            torch.cuda.set_rng_state(rng, x.device)
         return self._graphs[key]
 
     def train_epoch(self, train_loader):
