@@ -69,8 +69,9 @@ typedef struct vg_wgrad_desc {
     int32_t per_group;
 } vg_wgrad_desc;
 int64_t vg_wgrad3d_ws_bytes(const vg_wgrad_desc* d);
+/* accumulate != 0: dw += result (lets the caller point dw at the parameter's .grad and skip a separate add) */
 int vg_wgrad3d(const vg_wgrad_desc* d, const float* a, const float* b, const float* in_scale,
-               const float* in_shift, float* ws, float* dw, void* stream);
+               const float* in_shift, float* ws, float* dw, int32_t accumulate, void* stream);
 
 /* batch-norm batch statistics (BatchNorm3d(track_running_stats=False), vae_reg_GP.py:194-196,
  * 216-218): for x [N][C][P], group g = n / per_group: mean/var over (per_group samples, P) of
@@ -97,7 +98,7 @@ int vg_bn_bwd_apply(float* dxe_inout, const float* p, int32_t N, int32_t C, int6
                     const double* sums, double count, float* dgamma_part, float* dbeta_part, void* stream);
 
 /* per-channel sum of a [N][C][P] tensor (bias gradients): out[c] = sum_{n,p} x[n][c][p] */
-int vg_channel_sum(const float* x, int32_t N, int32_t C, int64_t P, void* ws, float* out, void* stream);
+int vg_channel_sum(const float* x, int32_t N, int32_t C, int64_t P, void* ws, float* out, int32_t accumulate, void* stream);
 
 /* fused GAM accumulate + ELBO + GLM distance (vae_reg_GP.py:380,388-390,400-406).
  *   logits [G=C+1][B][V]: decoder pre-sigmoid outputs (group 0 = base map, group i = effect map i)

@@ -34,13 +34,13 @@ _PROTOS = {
     'vg_corr3d': (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
     'vg_tconv3d_s2': (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
     'vg_wgrad3d_ws_bytes': (i64, [ctypes.POINTER(WgradDesc)]),
-    'vg_wgrad3d': (ctypes.c_int, [ctypes.POINTER(WgradDesc), vp, vp, vp, vp, vp, vp, vp]),
+    'vg_wgrad3d': (ctypes.c_int, [ctypes.POINTER(WgradDesc), vp, vp, vp, vp, vp, vp, i32, vp]),
     'vg_bn_ws_bytes': (i64, [i32, i32, i64, i32]),
     'vg_bn_stats': (ctypes.c_int, [vp, i32, i32, i64, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),
     'vg_bn_finalize': (ctypes.c_int, [vp, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp]),
     'vg_bn_bwd_reduce': (ctypes.c_int, [vp, vp, i32, i32, i64, i32, i32, vp, vp, vp, vp, vp]),
     'vg_bn_bwd_apply': (ctypes.c_int, [vp, vp, i32, i32, i64, i32, i32, vp, vp, vp, vp, f64, vp, vp, vp]),
-    'vg_channel_sum': (ctypes.c_int, [vp, i32, i32, i64, vp, vp, vp]),
+    'vg_channel_sum': (ctypes.c_int, [vp, i32, i32, i64, vp, vp, i32, vp]),
     'vg_gam_ws_bytes': (i64, [i32, i32, i64]),
     'vg_gam_elbo_fwd': (ctypes.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, vp]),
     'vg_gam_elbo_bwd': (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, vp]),

@@ -72,14 +72,18 @@ bn_partial_k(const float* __restrict__ x, const float* __restrict__ p, const flo
     }
 }
 
-// one thread per (g,c): fold the chunk partials; NOUT = 3 writes [s0, s1, count], NOUT = 2 writes [s0, s1]
-__global__ void bn_fold_k(const double* __restrict__ part, int GC, int chunks, double count, int nout, double* __restrict__ sums) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= GC) return;
+// one WAVE per (g,c): fold the chunk partials in a fixed order (lane-strided partial sums, then the shuffle tree);
+// nout = 3 writes [s0, s1, count], nout = 2 writes [s0, s1]
+__global__ void __launch_bounds__(64)
+bn_fold_k(const double* __restrict__ part, int GC, int chunks, double count, int nout, double* __restrict__ sums) {
+    const int i = blockIdx.x, lane = threadIdx.x;
     double a = 0, b = 0;
-    for (int k = 0; k < chunks; ++k) { a += part[((size_t)i * chunks + k) * 2]; b += part[((size_t)i * chunks + k) * 2 + 1]; }
-    sums[(size_t)i * nout] = a; sums[(size_t)i * nout + 1] = b;
-    if (nout == 3) sums[(size_t)i * nout + 2] = count;
+    for (int k = lane; k < chunks; k += VG_WAVE) { a += part[((size_t)i * chunks + k) * 2]; b += part[((size_t)i * chunks + k) * 2 + 1]; }
+    a = wave_sum(a); b = wave_sum(b);
+    if (lane == 0) {
+        sums[(size_t)i * nout] = a; sums[(size_t)i * nout + 1] = b;
+        if (nout == 3) sums[(size_t)i * nout + 2] = count;
+    }
 }
 
 __global__ void bn_finalize_k(const double* __restrict__ sums, int G, int C, const float* __restrict__ gamma,
@@ -184,7 +188,7 @@ extern "C" int vg_bn_stats(const float* x, int32_t N, int32_t C, int64_t P, int3
     vg_launch(bn_partial_k<0>, dim3(chunks, C, G), dim3(BN_THREADS), 0, s, x, (const float*)nullptr, (const float*)nullptr,
               (const float*)nullptr, (int)C, (long long)P, (int)per_group, (int)relu, pl.cp, part);
     if ((rc = vg_check_launch("bn_partial"))) return rc;
-    vg_launch(bn_fold_k, dim3(vg_cdiv(G * C, 64)), dim3(64), 0, s, (const double*)part, G * C, chunks, (double)total, 3, sums);
+    vg_launch(bn_fold_k, dim3(G * C), dim3(64), 0, s, (const double*)part, G * C, chunks, (double)total, 3, sums);
     if ((rc = vg_check_launch("bn_fold"))) return rc;
     if (ext_sums) return VG_OK;                       // caller all-reduces, then calls vg_bn_finalize
     return vg_bn_finalize(sums, G, C, gamma, beta, eps, scale, shift, mean, rstd, stream);
@@ -204,7 +208,7 @@ extern "C" int vg_bn_bwd_reduce(const float* dxe, const float* p, int32_t N, int
     vg_launch(bn_partial_k<1>, dim3(chunks, C, G), dim3(BN_THREADS), 0, s, dxe, p, mean, rstd, (int)C, (long long)P,
               (int)per_group, (int)relu, pl.cp, part);
     if ((rc = vg_check_launch("bn_bwd_partial"))) return rc;
-    vg_launch(bn_fold_k, dim3(vg_cdiv(G * C, 64)), dim3(64), 0, s, (const double*)part, G * C, chunks, (double)total, 2, sums);
+    vg_launch(bn_fold_k, dim3(G * C), dim3(64), 0, s, (const double*)part, G * C, chunks, (double)total, 2, sums);
     return vg_check_launch("bn_bwd_fold");
 }
 
@@ -222,17 +226,18 @@ extern "C" int vg_bn_bwd_apply(float* dxe, const float* p, int32_t N, int32_t C,
 }
 
 namespace {
-__global__ void chsum_fold_k(const double* __restrict__ part, int C, int chunks, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ void __launch_bounds__(64)
+chsum_fold_k(const double* __restrict__ part, int C, int chunks, int accumulate, float* __restrict__ out) {
+    const int c = blockIdx.x, lane = threadIdx.x;
     double a = 0;
-    for (int k = 0; k < chunks; ++k) a += part[((size_t)c * chunks + k) * 2];
-    out[c] = (float)a;
+    for (int k = lane; k < chunks; k += VG_WAVE) a += part[((size_t)c * chunks + k) * 2];
+    a = wave_sum(a);
+    if (lane == 0) out[c] = (accumulate ? out[c] : 0.f) + (float)a;
 }
 }  // namespace
 
 // x viewed as one group of N samples: per-channel sum (bias gradients)
-extern "C" int vg_channel_sum(const float* x, int32_t N, int32_t C, int64_t P, void* ws, float* out, void* stream) {
+extern "C" int vg_channel_sum(const float* x, int32_t N, int32_t C, int64_t P, void* ws, float* out, int32_t accumulate, void* stream) {
     int rc = bn_args_ok("vg_channel_sum", x, N, C, P, N);
     if (rc) return rc;
     if (!ws || !out) { vg_set_error("vg_channel_sum: null argument"); return VG_ERR_ARG; }
@@ -243,6 +248,6 @@ extern "C" int vg_channel_sum(const float* x, int32_t N, int32_t C, int64_t P, v
     vg_launch(bn_partial_k<0>, dim3(chunks, C, 1), dim3(BN_THREADS), 0, s, x, (const float*)nullptr, (const float*)nullptr,
               (const float*)nullptr, (int)C, (long long)P, (int)N, 0, pl.cp, part);
     if ((rc = vg_check_launch("channel_sum partial"))) return rc;
-    vg_launch(chsum_fold_k, dim3(vg_cdiv(C, 64)), dim3(64), 0, s, (const double*)part, (int)C, chunks, out);
+    vg_launch(chsum_fold_k, dim3(C), dim3(64), 0, s, (const double*)part, (int)C, chunks, (int)accumulate, out);
     return vg_check_launch("channel_sum fold");
 }

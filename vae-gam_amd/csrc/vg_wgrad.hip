@@ -195,18 +195,31 @@ wgrad_own_k(const float* __restrict__ a, const float* __restrict__ b, const floa
     }
 }
 
-// sum `nslab` slabs of `len` floats in slab order (fixed order => run-to-run reproducible)
-__global__ void __launch_bounds__(256) slab_sum_k(const float* __restrict__ ws, int nslab, int len, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= len) return;
+// sum `nslab` slabs of `len` floats in a fixed order (run-to-run reproducible): a block owns 64 outputs, its 16
+// thread rows take slabs r, r+16, ... (4 running sums each), LDS tree over the rows; optionally += into out
+constexpr int SLAB_ROWS = 16;
+__global__ void __launch_bounds__(64 * SLAB_ROWS)
+slab_sum_k(const float* __restrict__ ws, int nslab, int len, int accumulate, float* __restrict__ out) {
+    __shared__ float red[SLAB_ROWS][64];
+    const int j = threadIdx.x % 64, r = threadIdx.x / 64;
+    const int i = blockIdx.x * 64 + j;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 3 < nslab; k += 4) {
-        s0 += ws[(size_t)k * len + i]; s1 += ws[(size_t)(k + 1) * len + i];
-        s2 += ws[(size_t)(k + 2) * len + i]; s3 += ws[(size_t)(k + 3) * len + i];
+    if (i < len) {
+        int k = r;
+        for (; k + 3 * SLAB_ROWS < nslab; k += 4 * SLAB_ROWS) {
+            s0 += ws[(size_t)k * len + i]; s1 += ws[(size_t)(k + SLAB_ROWS) * len + i];
+            s2 += ws[(size_t)(k + 2 * SLAB_ROWS) * len + i]; s3 += ws[(size_t)(k + 3 * SLAB_ROWS) * len + i];
+        }
+        for (; k < nslab; k += SLAB_ROWS) s0 += ws[(size_t)k * len + i];
     }
-    for (; k < nslab; ++k) s0 += ws[(size_t)k * len + i];
-    out[i] = (s0 + s1) + (s2 + s3);
+    red[r][j] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (r == 0 && i < len) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < SLAB_ROWS; ++q) t += red[q][j];
+        out[i] = (accumulate ? out[i] : 0.f) + t;
+    }
 }
 
 constexpr int WG_MAX_BLOCKS = 512;
@@ -242,7 +255,7 @@ int plan_own(const vg_wgrad_desc* d, WgradParams& p, size_t& shmem, int& threads
 
 template <int CB, int CBT, int KD, int KH, int KW, int S, int TPW, bool OWN_KH>
 int launch_own(const vg_wgrad_desc* d, const float* a, const float* b, const float* in_scale, const float* in_shift,
-               float* ws, float* dw, hipStream_t s, int64_t* ws_bytes_only) {
+               float* ws, float* dw, hipStream_t s, int64_t* ws_bytes_only, int accumulate) {
     WgradParams p; size_t shmem; int threads, grid;
     int rc = plan_own<CB, CBT, KD, KH, KW, S, TPW, OWN_KH>(d, p, shmem, threads, grid);
     if (rc) return rc;
@@ -252,7 +265,7 @@ int launch_own(const vg_wgrad_desc* d, const float* a, const float* b, const flo
               a, b, in_scale, in_shift, ws, p);
     rc = vg_check_launch("wgrad_own");
     if (rc) return rc;
-    vg_launch(slab_sum_k, dim3(vg_cdiv(len, 256)), dim3(256), 0, s, (const float*)ws, grid * p.psplit, len, dw);
+    vg_launch(slab_sum_k, dim3(vg_cdiv(len, 64)), dim3(64 * SLAB_ROWS), 0, s, (const float*)ws, grid * p.psplit, len, accumulate, dw);
     return vg_check_launch("wgrad slab_sum");
 }
 
@@ -405,7 +418,7 @@ wgrad_mfma_k(const float* __restrict__ a, const float* __restrict__ b, const flo
 
 template <int NT, int KD, int KH, int KW, int S>
 int launch_mfma(const vg_wgrad_desc* d, const float* a, const float* b, const float* in_scale, const float* in_shift,
-                float* ws, float* dw, hipStream_t s, int64_t* ws_bytes_only) {
+                float* ws, float* dw, hipStream_t s, int64_t* ws_bytes_only, int accumulate) {
     WgradMfmaParams p; p.d = *d;
     constexpr int KVOL = KD * KH * KW;
     if (d->CA * KVOL > NT * 16 || d->CB > 16) { vg_set_error("wgrad_mfma: CA=%d CB=%d do not fit NT=%d", d->CA, d->CB, NT); return VG_ERR_UNSUPPORTED; }
@@ -437,7 +450,7 @@ int launch_mfma(const vg_wgrad_desc* d, const float* a, const float* b, const fl
     vg_launch(wgrad_mfma_k<NT, KD, KH, KW, S>, dim3(grid), dim3(256), shmem, s, a, b, in_scale, in_shift, ws, p);
     int rc = vg_check_launch("wgrad_mfma");
     if (rc) return rc;
-    vg_launch(slab_sum_k, dim3(vg_cdiv(len, 256)), dim3(256), 0, s, (const float*)ws, grid, len, dw);
+    vg_launch(slab_sum_k, dim3(vg_cdiv(len, 64)), dim3(64 * SLAB_ROWS), 0, s, (const float*)ws, grid, len, accumulate, dw);
     return vg_check_launch("wgrad slab_sum");
 }
 
@@ -593,7 +606,7 @@ wgrad_plane_k(const float* __restrict__ a, const float* __restrict__ b, const fl
 // returns -1 when the geometry does not fit (caller falls back)
 template <int CA, int TC, int KD, int KH, int KW, int S>
 int launch_plane(const vg_wgrad_desc* d, const float* a, const float* b, const float* in_scale, const float* in_shift,
-                 float* ws, float* dw, hipStream_t s, int64_t* ws_bytes_only) {
+                 float* ws, float* dw, hipStream_t s, int64_t* ws_bytes_only, int accumulate) {
     constexpr int KVOL = KD * KH * KW;
     constexpr int NT = CA * TC;
     if (d->pad_d || d->pad_h || d->pad_w || d->CA != CA || d->CB > 16) return -1;
@@ -634,7 +647,7 @@ int launch_plane(const vg_wgrad_desc* d, const float* a, const float* b, const f
     vg_launch(wgrad_plane_k<CA, TC, KD, KH, KW, S>, dim3(grid), dim3(256), fl * sizeof(float), s, a, b, in_scale, in_shift, ws, p);
     int rc = vg_check_launch("wgrad_plane");
     if (rc) return rc;
-    vg_launch(slab_sum_k, dim3(vg_cdiv(len, 256)), dim3(256), 0, s, (const float*)ws, grid, len, dw);
+    vg_launch(slab_sum_k, dim3(vg_cdiv(len, 64)), dim3(64 * SLAB_ROWS), 0, s, (const float*)ws, grid, len, accumulate, dw);
     return vg_check_launch("wgrad slab_sum");
 }
 
@@ -716,7 +729,7 @@ wgrad_wide_k(const float* __restrict__ a, const float* __restrict__ b, const flo
 }
 
 int launch_wide(const vg_wgrad_desc* d, const float* a, const float* b, const float* in_scale, const float* in_shift,
-                float* ws, float* dw, hipStream_t s, int64_t* ws_bytes_only) {
+                float* ws, float* dw, hipStream_t s, int64_t* ws_bytes_only, int accumulate) {
     constexpr int TW = 4;
     WideParams p; p.d = *d; p.wgroups = vg_cdiv(d->PW, TW);
     p.items = (long long)d->N * d->PD * d->PH * p.wgroups;
@@ -727,12 +740,12 @@ int launch_wide(const vg_wgrad_desc* d, const float* a, const float* b, const fl
     vg_launch(wgrad_wide_k<8, 3, 3, 3, TW>, dim3(grid), dim3(256), 0, s, a, b, in_scale, in_shift, ws, p);
     int rc = vg_check_launch("wgrad_wide");
     if (rc) return rc;
-    vg_launch(slab_sum_k, dim3(vg_cdiv(len, 256)), dim3(256), 0, s, (const float*)ws, grid, len, dw);
+    vg_launch(slab_sum_k, dim3(vg_cdiv(len, 64)), dim3(64 * SLAB_ROWS), 0, s, (const float*)ws, grid, len, accumulate, dw);
     return vg_check_launch("wgrad slab_sum");
 }
 
 int dispatch(const vg_wgrad_desc* d, const float* a, const float* b, const float* in_scale, const float* in_shift,
-             float* ws, float* dw, hipStream_t s, int64_t* ws_only) {
+             float* ws, float* dw, hipStream_t s, int64_t* ws_only, int accumulate) {
     if (!d) { vg_set_error("vg_wgrad3d: null descriptor"); return VG_ERR_ARG; }
     if (d->N <= 0 || d->CA <= 0 || d->CB <= 0 || d->PD <= 0 || d->PH <= 0 || d->PW <= 0 || d->AD <= 0 || d->AH <= 0 ||
         d->AW <= 0 || (d->stride != 1 && d->stride != 2)) {
@@ -744,7 +757,7 @@ int dispatch(const vg_wgrad_desc* d, const float* a, const float* b, const float
     const bool k333 = d->KD == 3 && d->KH == 3 && d->KW == 3;
     const bool small_w = d->PW <= 8;
 #define PLANE(CA, TC, KD, KH, KW, S) \
-    { int r_ = launch_plane<CA, TC, KD, KH, KW, S>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only); if (r_ >= 0) return r_; }
+    { int r_ = launch_plane<CA, TC, KD, KH, KW, S>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; }
     if (d->CB <= 16 && d->PW <= 64) {
         // (CA == 1, conv1 / convt5: the row-blocked plane variant measured slower than the wide VALU kernel below)
         if (k333 && d->CA == 8 && d->stride == 1) PLANE(8, 2, 3, 3, 3, 1);
@@ -757,9 +770,9 @@ int dispatch(const vg_wgrad_desc* d, const float* a, const float* b, const float
 #undef PLANE
     if (d->CB == 8 && d->CA == 1 && k333 && d->stride == 1 && d->pad_d == 0 && d->pad_h == 0 && d->pad_w == 0 &&
         d->AD >= d->PD + 2 && d->AH >= d->PH + 2)
-        return launch_wide(d, a, b, in_scale, in_shift, ws, dw, s, ws_only);
+        return launch_wide(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate);
 #define MFMA(NT, KD, KH, KW, S) \
-    return launch_mfma<NT, KD, KH, KW, S>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only)
+    return launch_mfma<NT, KD, KH, KW, S>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate)
     if (false && d->CB <= 16 && d->PW <= 64) {
         if (k333 && d->CA == 8 && d->stride == 1) MFMA(14, 3, 3, 3, 1);
         if (k333 && d->CA == 8 && d->stride == 2) MFMA(14, 3, 3, 3, 2);
@@ -770,7 +783,7 @@ int dispatch(const vg_wgrad_desc* d, const float* a, const float* b, const float
     }
 #undef MFMA
 #define OWN(CB, CBT, KD, KH, KW, S, TPW, OKH) \
-    return launch_own<CB, CBT, KD, KH, KW, S, TPW, OKH>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only)
+    return launch_own<CB, CBT, KD, KH, KW, S, TPW, OKH>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate)
     if (k333 && d->CB == 16 && d->CA == 16 && d->stride == 1) { if (small_w) OWN(16, 4, 3, 3, 3, 1, 8, false); OWN(16, 4, 3, 3, 3, 1, 16, false); }
     if (k333 && d->CB == 16 && d->CA == 16 && d->stride == 2) { if (small_w) OWN(16, 4, 3, 3, 3, 2, 8, false); OWN(16, 4, 3, 3, 3, 2, 16, false); }
     if (k333 && d->CB == 16 && d->CA == 8 && d->stride == 1) { if (small_w) OWN(16, 4, 3, 3, 3, 1, 8, false); OWN(16, 4, 3, 3, 3, 1, 16, false); }
@@ -787,12 +800,12 @@ int dispatch(const vg_wgrad_desc* d, const float* a, const float* b, const float
 
 extern "C" int64_t vg_wgrad3d_ws_bytes(const vg_wgrad_desc* d) {
     int64_t bytes = 0;
-    int rc = dispatch(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &bytes);
+    int rc = dispatch(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &bytes, 0);
     return rc ? -1 : bytes;
 }
 
 extern "C" int vg_wgrad3d(const vg_wgrad_desc* d, const float* a, const float* b, const float* in_scale,
-                          const float* in_shift, float* ws, float* dw, void* stream) {
+                          const float* in_shift, float* ws, float* dw, int32_t accumulate, void* stream) {
     if (!a || !b || !ws || !dw) { vg_set_error("vg_wgrad3d: null argument"); return VG_ERR_ARG; }
-    return dispatch(d, a, b, in_scale, in_shift, ws, dw, (hipStream_t)stream, nullptr);
+    return dispatch(d, a, b, in_scale, in_shift, ws, dw, (hipStream_t)stream, nullptr, accumulate);
 }

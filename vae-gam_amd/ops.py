@@ -149,7 +149,7 @@ def conv_backward_data(dy, wpk_bwd, spec: ConvSpec, in_size, mask_src=None):
     return dx
 
 
-def conv_weight_grad(x, dy, spec: ConvSpec, relu_in=False, scale=None, shift=None, per_group=1):
+def conv_weight_grad(x, dy, spec: ConvSpec, relu_in=False, scale=None, shift=None, per_group=1, out=None):
     """dL/dW in the layer's own weight layout; the prologue of the forward is re-applied to x on load."""
     lib = _lib.get_lib()
     N = x.shape[0]
@@ -165,8 +165,12 @@ def conv_weight_grad(x, dy, spec: ConvSpec, relu_in=False, scale=None, shift=Non
         shape = (spec.ci, spec.co) + tuple(spec.k)
     nbytes = lib.size('vg_wgrad3d_ws_bytes', ctypes.byref(d))
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=x.device)
+    if out is not None:          # accumulate straight into the parameter's .grad (a view of the flat gradient buffer)
+        assert out.shape == shape and out.is_contiguous() and out.dtype == torch.float32
+        _call(x, 'vg_wgrad3d', ctypes.byref(d), _p(a), _p(b), _p(scale), _p(shift), _p(ws), _p(out), 1)
+        return None
     dw = torch.empty(shape, dtype=torch.float32, device=x.device)
-    _call(x, 'vg_wgrad3d', ctypes.byref(d), _p(a), _p(b), _p(scale), _p(shift), _p(ws), _p(dw))
+    _call(x, 'vg_wgrad3d', ctypes.byref(d), _p(a), _p(b), _p(scale), _p(shift), _p(ws), _p(dw), 0)
     return dw
 
 
@@ -224,13 +228,17 @@ def bn_backward_(dxe, p, gamma, mean, rstd, relu, per_group, sync=None):
     return parts[0].sum(0), parts[1].sum(0)
 
 
-def channel_sum(x):
+def channel_sum(x, out=None):
     lib = _lib.get_lib()
     N, C = x.shape[0], x.shape[1]
     P = x[0, 0].numel()
     ws = _bn_ws(x, N, C, P, N)
+    if out is not None:          # accumulate into an existing buffer (a bias .grad)
+        assert out.shape == (C,) and out.is_contiguous() and out.dtype == torch.float32
+        _call(x, 'vg_channel_sum', _p(_chk(x)), N, C, P, _p(ws), _p(out), 1)
+        return None
     out = torch.empty(C, dtype=torch.float32, device=x.device)
-    _call(x, 'vg_channel_sum', _p(_chk(x)), N, C, P, _p(ws), _p(out))
+    _call(x, 'vg_channel_sum', _p(_chk(x)), N, C, P, _p(ws), _p(out), 0)
     return out
 
 
@@ -257,6 +265,7 @@ class BnConvAct(torch.autograd.Function):
         ctx.spec, ctx.relu_in, ctx.per_group, ctx.input_is_data, ctx.sync, ctx.has_bn = \
             spec, relu_in, per_group, input_is_data, sync, has_bn
         ctx.save_for_backward(p_in, weight, gamma, beta, scale, shift, mean, rstd)
+        ctx.bias_ref = bias
         return y
 
     @staticmethod
@@ -269,7 +278,13 @@ class BnConvAct(torch.autograd.Function):
         p_in, weight, gamma, beta, scale, shift, mean, rstd = ctx.saved_tensors
         spec, relu_in, per_group = ctx.spec, ctx.relu_in, ctx.per_group
         dy = dy.contiguous()
-        db = channel_sum(dy)
+        # parameter gradients go straight into the parameters' .grad views of the flat gradient buffer when those
+        # exist (no separate accumulate kernels); autograd then gets None for them
+        wg = weight.grad if (isinstance(weight, torch.nn.Parameter) and weight.grad is not None and weight.grad.is_contiguous()) else None
+        bias_t = ctx.bias_ref
+        bg = bias_t.grad if (isinstance(bias_t, torch.nn.Parameter) and bias_t.grad is not None and bias_t.grad.is_contiguous()) else None
+        direct_db = bg is not None and not (ctx.input_is_data and ctx.has_bn)
+        db = channel_sum(dy, out=bg) if direct_db else channel_sum(dy)
         dgamma = dbeta = dp = None
         if ctx.input_is_data:
             if ctx.has_bn:
@@ -284,9 +299,9 @@ class BnConvAct(torch.autograd.Function):
                 dgamma = (weight * dw_hat).sum((0, 2, 3, 4))
                 dbeta = (weight.sum((2, 3, 4)) * db.view(-1, 1)).sum(0)
             else:
-                dw = conv_weight_grad(p_in, dy, spec, relu_in, None, None, per_group)
+                dw = conv_weight_grad(p_in, dy, spec, relu_in, None, None, per_group, out=wg)
             return None, dw, db, dgamma, dbeta, None, None, None, None, None
-        dw = conv_weight_grad(p_in, dy, spec, relu_in, scale, shift, per_group)
+        dw = conv_weight_grad(p_in, dy, spec, relu_in, scale, shift, per_group, out=wg)
         wb = pack_weight(weight, spec, 'bwd')
         in_size = tuple(p_in.shape[2:])
         if ctx.has_bn:
