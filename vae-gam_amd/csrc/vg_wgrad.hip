@@ -455,27 +455,31 @@ int launch_mfma(const vg_wgrad_desc* d, const float* a, const float* b, const fl
 }
 
 // ------------------------------------------------------------------------------------------
-// Plane-staged MFMA variant (pad == 0, every layer of the 41x49x35 network but convt2).
-// Same GEMM as above, but the im2col operand comes from WHOLE input planes of one `a` channel at a time:
-// the LD planes a block of TPD position planes needs are one contiguous span of the tensor, copied flat into
-// LDS by LDS-DMA (double-buffered over the channel loop, which is fully unrolled so that the accumulator
-// tiles of channel ca are named registers), raw; ReLU / batch-norm affine of `a` are applied to the operand
-// on its way from LDS into the MFMA (3 VALU ops beside a 32-cycle matrix instruction).  The b tile
-// ([position][16 channels], prologue applied while staging) is filled once per item by flat coalesced copies.
+// Plane-staged MFMA variant (every layer of the 41x49x35 network).
+// Same GEMM as above, but both operands come from LDS images that keep the TENSORS' OWN pitches and are filled
+// by flat LDS-DMA copies (global_load_lds_dword, contiguous 256-byte wave-instructions, no VGPR round trip, no
+// index arithmetic per element):
+//   a slot : the LD whole planes of ONE `a` channel that a block of TPD position planes needs (one contiguous
+//            span), double-buffered over the channel loop, which is fully unrolled so that the accumulator tiles
+//            of channel ca are named registers;
+//   b tile : for each of the (<=16) `b` channels the rows [ph0, ph0+TPH) of the TPD position planes (contiguous).
+// Positions are walked as groups of 4 consecutive FLAT (row-major) positions; a lane carries its (dz,py,px)
+// incrementally.  ReLU / batch-norm affine are applied to an operand on its way from LDS into the MFMA (VALU work
+// beside a 32-cycle matrix instruction); PAD adds the range masks of ConvTranspose3d padding (convt2).
 // ------------------------------------------------------------------------------------------
 struct WgradPlaneParams {
     vg_wgrad_desc d;
-    int TPD, TPH, TPWp;         // position planes / rows per b tile; PW rounded up to a multiple of 4
-    int nph;                    // row blocks per plane block (> 1 only when CA == 1)
+    int TPD, TPH;               // position planes / rows per b tile
+    int nph;                    // row blocks per plane block
     int LD;                     // a planes per item
     int a_slot;                 // floats per a buffer (LD*AH*AW + slack, multiple of 64)
     int nbuf;                   // 2: next channel's planes are DMA'd behind the MFMAs; 1: LDS too small for that
-    int b_off;                  // float offset of the b tile
+    int b_off, bch;             // float offset of the b tile; floats per b channel (== 2 mod 32: conflict-free operand reads)
     int lds_floats;             // total dynamic LDS floats
     int items, pdblocks;
 };
 
-template <int CA, int TC, int KD, int KH, int KW, int S>
+template <int CA, int TC, int KD, int KH, int KW, int S, bool PAD>
 __global__ void __launch_bounds__(256)
 wgrad_plane_k(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ in_scale,
               const float* __restrict__ in_shift, float* __restrict__ ws, WgradPlaneParams p) {
@@ -489,79 +493,95 @@ wgrad_plane_k(const float* __restrict__ a, const float* __restrict__ b, const fl
     float* btile = lds + p.b_off;
     const int aplane = d.AH * d.AW, bplane = d.PH * d.PW;
 
-    for (int i = tid; i < p.lds_floats; i += blockDim.x) lds[i] = 0.f;       // slack / padding entries stay finite (zero)
+    for (int i = tid; i < p.lds_floats; i += blockDim.x) lds[i] = 0.f;       // slack / unused channels stay finite (zero)
 
     int colOff[TC];                               // offset of tap (16 t + lane%16) inside an a channel, tensor pitches
+    int tkd[TC], tkh[TC], tkw[TC];
 #pragma unroll
     for (int t = 0; t < TC; ++t) {
         const int tap = t * 16 + (lane & 15);
-        colOff[t] = (tap < KVOL) ? ((tap / (KH * KW)) * d.AH + (tap / KW) % KH) * d.AW + tap % KW : 0;
+        const bool ok = tap < KVOL;
+        tkd[t] = ok ? tap / (KH * KW) : 0; tkh[t] = ok ? (tap / KW) % KH : 0; tkw[t] = ok ? tap % KW : 0;
+        colOff[t] = (tkd[t] * d.AH + tkh[t]) * d.AW + tkw[t];
     }
     vg_f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) { acc[t].v[0] = 0.f; acc[t].v[1] = 0.f; acc[t].v[2] = 0.f; acc[t].v[3] = 0.f; }
 
     const int rl_a = d.pro_on_a ? d.relu_in : 0, rl_b = d.pro_on_a ? 0 : d.relu_in;
-    const float lo_a = rl_a ? 0.f : -__builtin_inff();
-    const int gw = p.TPWp / 4;
-    const int groups = p.TPD * p.TPH * gw;
-    const int kq = lane >> 4;
+    const float lo_a = rl_a ? 0.f : -__builtin_inff(), lo_b = rl_b ? 0.f : -__builtin_inff();
+    const int npos = p.TPD * p.TPH * d.PW;                                 // flat positions of one b tile
+    const int groups = (npos + 3) / 4;
+    const int kq = lane >> 4, cbl = lane & 15;
+    // first flat position of this lane and its (dz, py, px); advanced by 4*nwaves per group
+    int px0, py0, dz0;
+    { const int pf = wave * 4 + kq; px0 = pf % d.PW; const int t2 = pf / d.PW; py0 = t2 % p.TPH; dz0 = t2 / p.TPH; }
+    const int step = 4 * nwaves;
     __syncthreads();
     for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
         const int n = item / p.pdblocks; const int pd0 = (item % p.pdblocks) * p.TPD;
         const int g = (in_scale != nullptr) ? n / d.per_group : 0;
-        const int ap0 = pd0 * S;                                          // first a plane (pad == 0)
-        const int nfl = max(min(ap0 + p.LD, d.AD) - ap0, 0) * aplane;     // floats per a channel for this item
-        const float* abase = a + (size_t)n * CA * d.AD * aplane + (size_t)ap0 * aplane;
+        const int ap0 = pd0 * S - d.pad_d;                                // first a plane the tile touches (may be < 0)
+        const int pl_lo = max(ap0, 0), pl_hi = min(ap0 + p.LD, d.AD);
+        const int nfl = max(pl_hi - pl_lo, 0) * aplane;                   // floats per a channel for this item
+        const int adst = (pl_lo - ap0) * aplane;                          // where they land inside the slot
+        const float* abase = a + (size_t)n * CA * d.AD * aplane + (size_t)pl_lo * aplane;
+        float bsc = 1.f, bsh = 0.f;
+        if (!d.pro_on_a && in_scale && cbl < CB) { bsc = in_scale[g * CB + cbl]; bsh = in_shift[g * CB + cbl]; }
         __syncthreads();                                                  // previous item's tiles fully consumed
         // ---- DMA of a channel 0 into buffer 0
         for (int o = wave * VG_WAVE; o < nfl; o += blockDim.x)
-            if (o + lane < nfl) vg_dma4(abase + o + lane, lds + o);
+            if (o + lane < nfl) vg_dma4(abase + o + lane, lds + adst + o);
         for (int phb = 0; phb < p.nph; ++phb) {
             const int ph0 = phb * p.TPH;
             const int nrow = min(p.TPH, d.PH - ph0);                      // valid rows of this block
-            // ---- b tile: rows [ph0, ph0+nrow) of TPD planes, flat coalesced copy per channel -> [position][16]
-            //      (a row-per-wave fill without the index divisions measured 10-60 % slower: rows are 14-33 wide)
-            {
-                const int per_plane = p.TPH * d.PW;
-                const int npos = p.TPD * per_plane;
-                for (int c = 0; c < CB; ++c) {
-                    float sc = 1.f, sh = 0.f;
-                    if (!d.pro_on_a && in_scale) { sc = in_scale[g * CB + c]; sh = in_shift[g * CB + c]; }
-                    const float* src = b + (((size_t)n * CB + c) * d.PD + pd0) * bplane + (size_t)ph0 * d.PW;
-                    for (int f = tid; f < npos; f += blockDim.x) {
-                        const int dz = f / per_plane, r = f % per_plane;
-                        const int py = r / d.PW, pw = r % d.PW;
-                        const bool ok = pd0 + dz < d.PD && py < nrow;
-                        const float v = ok ? apply_pro(src[(size_t)dz * bplane + r], rl_b, sc, sh) : 0.f;
-                        btile[((size_t)(dz * p.TPH + py) * p.TPWp + pw) * 16 + c] = v;
-                    }
+            // ---- b tile: per (channel, plane) one contiguous span of rows, flat DMA, tensor pitch
+            for (int c = 0; c < CB; ++c)
+                for (int dz = 0; dz < p.TPD; ++dz) {
+                    if (pd0 + dz >= d.PD) continue;
+                    const float* src = b + (((size_t)n * CB + c) * d.PD + pd0 + dz) * bplane + (size_t)ph0 * d.PW;
+                    float* dst = btile + c * p.bch + dz * p.TPH * d.PW;
+                    const int nb = nrow * d.PW;
+                    for (int o = wave * VG_WAVE; o < nb; o += blockDim.x)
+                        if (o + lane < nb) vg_dma4(src + o + lane, dst + o);
                 }
-            }
             vg_dma_wait();
             __syncthreads();
 #pragma unroll
             for (int ca = 0; ca < CA; ++ca) {
                 float* cur = lds + (ca % p.nbuf) * p.a_slot;
                 if (ca + 1 < CA && p.nbuf == 2) {                         // next channel in flight behind this channel's MFMAs
-                    float* nxt = lds + ((ca + 1) & 1) * p.a_slot;
+                    float* nxt = lds + ((ca + 1) & 1) * p.a_slot + adst;
                     const float* src = abase + (size_t)(ca + 1) * d.AD * aplane;
                     for (int o = wave * VG_WAVE; o < nfl; o += blockDim.x)
                         if (o + lane < nfl) vg_dma4(src + o + lane, nxt + o);
                 }
                 float sc = 1.f, sh = 0.f;
                 if (d.pro_on_a && in_scale) { sc = in_scale[g * CA + ca]; sh = in_shift[g * CA + ca]; }
+                int px = px0, py = py0, dz = dz0;
                 for (int gi = wave; gi < groups; gi += nwaves) {
-                    const int gx = gi % gw; const int t2 = gi / gw; const int py = t2 % p.TPH; const int pz = t2 / p.TPH;
-                    const int px = gx * 4 + kq;
-                    const float av = btile[((size_t)(pz * p.TPH + py) * p.TPWp + px) * 16 + (lane & 15)];
-                    const float* ap = cur + (pz * S) * aplane + ((ph0 + py) * S) * d.AW + px * S;
+                    const bool pok = dz < p.TPD && pd0 + dz < d.PD && py < nrow;       // this lane's position exists
+                    // b operand: channel cbl at this lane's position (prologue applied; zero for missing positions)
+                    float av = btile[min(cbl, CB - 1) * p.bch + (dz * p.TPH + py) * d.PW + px];   // only CB channel slots exist
+                    av = (pok && cbl < CB) ? fmaf(fmaxf(av, lo_b), bsc, bsh) : 0.f;
+                    const int idb = dz * S, ihb = (ph0 + py) * S - d.pad_h, iwb = px * S - d.pad_w;   // a coords of tap 0 (d relative to ap0)
+                    const float* ap = cur + idb * aplane + ihb * d.AW + iwb;
 #pragma unroll
                     for (int t = 0; t < TC; ++t) {
-                        float bv = ap[colOff[t]];
-                        if (d.pro_on_a) bv = fmaf(fmaxf(bv, lo_a), sc, sh);
+                        float bv;
+                        if (PAD) {
+                            const int id = ap0 + idb + tkd[t], ih = ihb + tkh[t], iw = iwb + tkw[t];
+                            const bool ok = pok && id >= 0 && id < d.AD && ih >= 0 && ih < d.AH && iw >= 0 && iw < d.AW;
+                            bv = ok ? ap[colOff[t]] : 0.f;
+                            if (d.pro_on_a) bv = ok ? fmaf(fmaxf(bv, lo_a), sc, sh) : 0.f;
+                        } else {
+                            bv = pok ? ap[colOff[t]] : 0.f;
+                            if (d.pro_on_a) bv = fmaf(fmaxf(bv, lo_a), sc, sh);
+                        }
                         vg_mfma16(av, bv, acc[ca * TC + t]);
                     }
+                    px += step;
+                    while (px >= d.PW) { px -= d.PW; if (++py == p.TPH) { py = 0; ++dz; } }
                 }
                 if (CA > 1) {
                     if (p.nbuf == 2) { vg_dma_wait(); __syncthreads(); }
@@ -569,13 +589,17 @@ wgrad_plane_k(const float* __restrict__ a, const float* __restrict__ b, const fl
                         __syncthreads();
                         const float* src = abase + (size_t)(ca + 1) * d.AD * aplane;
                         for (int o = wave * VG_WAVE; o < nfl; o += blockDim.x)
-                            if (o + lane < nfl) vg_dma4(src + o + lane, lds + o);
+                            if (o + lane < nfl) vg_dma4(src + o + lane, lds + adst + o);
                         vg_dma_wait();
                         __syncthreads();
                     }
                 }
             }
-            if (p.nph > 1) __syncthreads();                               // b tile is restaged for the next row block
+            if (p.nph > 1 || CA == 1) __syncthreads();                    // tiles are restaged next
+            if (CA > 1 && p.nph > 1 && phb + 1 < p.nph) {                 // channel 0 again for the next row block
+                for (int o = wave * VG_WAVE; o < nfl; o += blockDim.x)
+                    if (o + lane < nfl) vg_dma4(abase + o + lane, lds + adst + o);
+            }
         }
     }
     // ---- cross-wave reduction through LDS (one wave at a time), then one slab per block
@@ -604,39 +628,37 @@ wgrad_plane_k(const float* __restrict__ a, const float* __restrict__ b, const fl
 }
 
 // returns -1 when the geometry does not fit (caller falls back)
-template <int CA, int TC, int KD, int KH, int KW, int S>
+template <int CA, int TC, int KD, int KH, int KW, int S, bool PAD>
 int launch_plane(const vg_wgrad_desc* d, const float* a, const float* b, const float* in_scale, const float* in_shift,
                  float* ws, float* dw, hipStream_t s, int64_t* ws_bytes_only, int accumulate) {
     constexpr int KVOL = KD * KH * KW;
     constexpr int NT = CA * TC;
-    if (d->pad_d || d->pad_h || d->pad_w || d->CA != CA || d->CB > 16) return -1;
-    if ((d->PD - 1) * S + KD > d->AD || (d->PH - 1) * S + KH > d->AH || (d->PW - 1) * S + KW > d->AW) return -1;
+    const bool padded = d->pad_d || d->pad_h || d->pad_w;
+    if (padded != PAD || d->CA != CA || d->CB > 16) return -1;
+    if (!PAD && ((d->PD - 1) * S + KD > d->AD || (d->PH - 1) * S + KH > d->AH || (d->PW - 1) * S + KW > d->AW)) return -1;
     WgradPlaneParams p; p.d = *d;
-    p.TPWp = (d->PW + 3) & ~3;
     const int aplane = d->AH * d->AW;
     const size_t budget = 64 * 1024;
     const size_t red_fl = (size_t)NT * 4 * VG_WAVE;
-    auto slot_for = [&](int LD) { return (((size_t)LD * aplane + 2 * d->AW + 8 * S + 64 + 63) / 64) * 64; };
-    // preference: whole planes of positions with double-buffered a planes; then single-buffered; then (one `a`
-    // channel only) row blocks of the position plane
+    // slot: LD planes + slack for windows of masked / overhanging positions that run past the last (or before the first) plane
+    auto slot_for = [&](int LD) { return (((size_t)(LD + 1) * aplane + (size_t)KH * d->AW + 8 * S + 64 + 63) / 64) * 64; };
+    auto bch_for = [&](int td, int th) { size_t f = (size_t)td * th * d->PW + 4; while (f % 32 != 2) ++f; return f; };
     int best_td = 0, best_th = 0, best_nbuf = 0;
-    for (int nbuf = 2; nbuf >= 1 && !best_td; --nbuf)
-        for (int td = 1; td <= 8 && td <= d->PD; ++td) {
-            const size_t bfl = (size_t)td * d->PH * p.TPWp * 16;
-            if ((nbuf * slot_for((td - 1) * S + KD) + bfl + 64) * 4 <= budget) { best_td = td; best_th = d->PH; best_nbuf = nbuf; }
-        }
-    if (!best_td && CA == 1) {
-        for (int th = d->PH; th >= 1; --th) {
-            const size_t bfl = (size_t)th * p.TPWp * 16;
-            if ((slot_for(KD) + bfl + 64) * 4 <= budget) { best_td = 1; best_th = th; best_nbuf = 1; break; }
-        }
+    for (int nbuf = 2; nbuf >= 1 && !best_td; --nbuf) {
+        if (nbuf == 2 && CA == 1) continue;
+        for (int td = 1; td <= 8 && td <= d->PD; ++td)
+            if ((nbuf * slot_for((td - 1) * S + KD) + d->CB * bch_for(td, d->PH) + 64) * 4 <= budget) { best_td = td; best_th = d->PH; best_nbuf = nbuf; }
     }
+    if (!best_td)                                   // row blocks of one position plane, single a buffer
+        for (int th = d->PH; th >= 4; --th)
+            if ((slot_for(KD) + d->CB * bch_for(1, th) + 64) * 4 <= budget) { best_td = 1; best_th = th; best_nbuf = 1; break; }
     if (!best_td) return -1;
     p.TPD = best_td; p.TPH = best_th; p.nbuf = best_nbuf; p.nph = vg_cdiv(d->PH, p.TPH);
     p.LD = (p.TPD - 1) * S + KD;
     p.a_slot = (int)slot_for(p.LD);
+    p.bch = (int)bch_for(p.TPD, p.TPH);
     p.b_off = p.nbuf * p.a_slot;
-    size_t fl = (size_t)p.b_off + (size_t)p.TPD * p.TPH * p.TPWp * 16 + 64;
+    size_t fl = (size_t)p.b_off + (size_t)d->CB * p.bch + 64;
     if (fl < red_fl) fl = red_fl;
     p.lds_floats = (int)fl;
     p.pdblocks = vg_cdiv(d->PD, p.TPD);
@@ -644,7 +666,7 @@ int launch_plane(const vg_wgrad_desc* d, const float* a, const float* b, const f
     const int grid = p.items < 768 ? p.items : 768;
     const int len = d->CB * CA * KVOL;
     if (ws_bytes_only) { *ws_bytes_only = (int64_t)grid * len * sizeof(float); return VG_OK; }
-    vg_launch(wgrad_plane_k<CA, TC, KD, KH, KW, S>, dim3(grid), dim3(256), fl * sizeof(float), s, a, b, in_scale, in_shift, ws, p);
+    vg_launch(wgrad_plane_k<CA, TC, KD, KH, KW, S, PAD>, dim3(grid), dim3(256), fl * sizeof(float), s, a, b, in_scale, in_shift, ws, p);
     int rc = vg_check_launch("wgrad_plane");
     if (rc) return rc;
     vg_launch(slab_sum_k, dim3(vg_cdiv(len, 64)), dim3(64 * SLAB_ROWS), 0, s, (const float*)ws, grid, len, accumulate, dw);
@@ -757,9 +779,11 @@ int dispatch(const vg_wgrad_desc* d, const float* a, const float* b, const float
     const bool k333 = d->KD == 3 && d->KH == 3 && d->KW == 3;
     const bool small_w = d->PW <= 8;
 #define PLANE(CA, TC, KD, KH, KW, S) \
-    { int r_ = launch_plane<CA, TC, KD, KH, KW, S>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; }
+    { int r_ = launch_plane<CA, TC, KD, KH, KW, S, false>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; }
     if (d->CB <= 16 && d->PW <= 64) {
-        // (CA == 1, conv1 / convt5: the row-blocked plane variant measured slower than the wide VALU kernel below)
+        if (k333 && d->CA == 1 && d->stride == 1) PLANE(1, 2, 3, 3, 3, 1);
+        if (k333 && d->CA == 16 && d->stride == 2 && (d->pad_d || d->pad_h || d->pad_w))
+            { int r_ = launch_plane<16, 2, 3, 3, 3, 2, true>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; }
         if (k333 && d->CA == 8 && d->stride == 1) PLANE(8, 2, 3, 3, 3, 1);
         if (k333 && d->CA == 8 && d->stride == 2) PLANE(8, 2, 3, 3, 3, 2);
         if (k333 && d->CA == 16 && d->stride == 1) PLANE(16, 2, 3, 3, 3, 1);
