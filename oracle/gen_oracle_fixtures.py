@@ -36,6 +36,23 @@ def case_inputs(B=32, C=3, data_seed=3, noise_seed=5, model_seed=1, device='cpu'
     return ds, model, cfg, x, cov, noise
 
 
+def hires_inputs(B=2, C=12, img=(82, 98, 70), seed=9, noise_seed=6, model_seed=1, device='cpu'):
+    """BASELINE configs[4] geometry (82x98x70, 12 covariates; no reference counterpart) at a tiny batch."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    V = int(np.prod(img))
+    x = torch.from_numpy(np.clip(0.5 + 0.25 * rng.standard_normal((B,) + img), 0, 1).astype(np.float32))
+    cont = rng.standard_normal((B, C - 2)); cont[0] = 6.0; cont[1] = -4.0
+    cov = np.concatenate([(np.arange(B) % 2)[:, None], cont, (np.arange(B) % 2)[:, None]], 1).astype(np.float32)
+    xu = [[float(cont[:, j].min()) - 1e-3, float(cont[:, j].max()) + 1e-3] for j in range(C - 2)]
+    glm = rng.uniform(size=(V, C)); glm = glm / glm.max(0, keepdims=True)
+    glm = np.concatenate([np.arange(V, dtype=np.float64)[:, None], glm], 1)
+    torch.manual_seed(model_seed)
+    model = VAE(num_covariates=C, glm_maps=glm, xu_ranges=xu, device_name=device, img_shape=img)
+    cfg = bridge.oracle_config(model)
+    noise = O.draw_noise(B, cfg, torch.Generator().manual_seed(noise_seed))
+    return glm, model, cfg, x, torch.from_numpy(cov), noise
+
+
 def sample_idx(name, n, k=512):
     r = np.random.Generator(np.random.PCG64(zlib.crc32(name.encode())))
     return np.sort(r.choice(n, min(k, n), replace=False))
@@ -71,6 +88,23 @@ def main():
         arr['g.%s.val64' % k] = a64[idx]
         arr['g.%s.val32' % k] = a32[idx]
     out = os.path.join(ROOT, 'tests', 'golden', 'oracle_B32_C3.npz')
+    np.savez_compressed(out, **arr)
+    print('wrote', out, os.path.getsize(out))
+    # ---- hi-res geometry, fp32 oracle only
+    glm, model, cfg, x, cov, noise = hires_inputs()
+    params = bridge.params_from_model(model)
+    t = time.time()
+    out32, g32 = O.loss_and_grads(params, cfg, x, cov, torch.from_numpy(glm), noise)
+    print('hi-res fp32 oracle %.1fs' % (time.time() - t), flush=True)
+    arr = {'loss32': out32['loss'].detach().numpy(), 'slp32': out32['sum_log_prob'].detach().numpy(),
+           'z32': out32['z'].detach().numpy(), 'kl_z32': out32['kl_z'].detach().numpy()}
+    for k in g32:
+        if g32[k] is None:
+            continue
+        a32 = g32[k].double().flatten().numpy()
+        idx = sample_idx(k, a32.size, 256)
+        arr['g.%s.norm32' % k] = np.sqrt((a32 * a32).sum()); arr['g.%s.idx' % k] = idx; arr['g.%s.val32' % k] = a32[idx]
+    out = os.path.join(ROOT, 'tests', 'golden', 'oracle_hires_B2_C12.npz')
     np.savez_compressed(out, **arr)
     print('wrote', out, os.path.getsize(out))
 

@@ -135,6 +135,31 @@ def test_step_matches_oracle_B32_C3(golden_dir):
     print('worst grad error / band:', max(worst, key=worst.get), max(worst.values()))
 
 
+def test_hires_geometry_matches_oracle(golden_dir):
+    """BASELINE configs[4] geometry (82x98x70 volumes, 12 covariates with HRF on the first five) at batch 2 against
+    the fp32 CPU oracle (oracle/gen_oracle_fixtures.py): loss, per-sample log-likelihood, latents, and the weight /
+    bias gradient norms of every conv layer (rel 5e-3; the gain-coupled parameters are covered at 41x49x35)."""
+    import gen_oracle_fixtures as F
+    g = dict(np.load(os.path.join(golden_dir, 'oracle_hires_B2_C12.npz')))
+    glm, model, cfg, x, cov, noise = F.hires_inputs(device='cuda')
+    model.optimizer.zero_grad()
+    res = model.forward_core(cov.cuda(), x.cuda(), bridge.noise_to(noise, 'cuda'))
+    res['loss'].backward()
+    np.testing.assert_allclose(res['loss'].detach().cpu().numpy(), g['loss32'], rtol=2e-4)
+    np.testing.assert_allclose(res['sum_log_prob'].detach().cpu().numpy(), g['slp32'], rtol=2e-4)
+    np.testing.assert_allclose(res['z'].detach().cpu().numpy(), g['z32'], atol=1e-4)
+    byname = bridge.model_param_by_oracle_name(model)
+    for k, p in byname.items():
+        if ('g.%s.norm32' % k) not in g or not k.split('.')[0].startswith(('conv', 'bn')):
+            continue
+        a = p.grad.detach().double().cpu().flatten().numpy()
+        n32 = float(g['g.%s.norm32' % k])
+        np.testing.assert_allclose(np.sqrt((a * a).sum()), n32, rtol=5e-3, atol=1e-6, err_msg=k)
+        idx = g['g.%s.idx' % k]
+        err = np.sqrt(((a[idx] - g['g.%s.val32' % k]) ** 2).sum())
+        assert err <= 1e-2 * np.sqrt((g['g.%s.val32' % k] ** 2).sum()) + 1e-6, (k, err)
+
+
 def test_hipgraph_replay_equals_eager_launches():
     """Three train steps replayed from the captured hipGraph == the same three steps launched eagerly
     (same seeds, same minibatches): parameters and losses agree bit for bit."""
