@@ -157,6 +157,11 @@ def main():
         rows.append((tot, key, len(evs)))
     rows.sort(reverse=True)
     roofline = None
+    traffic_tab = {}
+    try:        # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, tools/profile_summary.py)
+        traffic_tab = json.load(open(os.path.join(ROOT, 'profiles', 'round1_traffic_by_layer.json')))
+    except Exception:
+        pass
     for tot, key, n in rows:
         ab = alg_bytes_per_launch(key, model, B)
         if ab is None:
@@ -164,7 +169,9 @@ def main():
         per = tot / n                                                # ms per launch
         ach = ab / (per * 1e-3) / 1e9
         roofline = {'bound': 'hbm', 'kernel': key, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None, 'alg_bytes_per_launch': ab,
+                    'frac': round(ach / HBM_PEAK_GBS, 4),
+                    'traffic': (traffic_tab.get(key) or {}).get('hbm_bytes_per_launch') if (B == 32 and C == 3) else None,
+                    'alg_bytes_per_launch': ab,
                     'avg_launch_us': round(per * 1e3, 2), 'launches': n,
                     'share_of_kernel_time': round(tot / max(sum(r[0] for r in rows), 1e-9), 3)}
         break
