@@ -436,6 +436,7 @@ class VAE(nn.Module):
         self.optimizer.zero_grad()
         loss = self.forward(ids, covariates, x, 'train', train_mode=True, noise=noise)
         loss.backward()
+        ops.join_side_stream(x.device)                      # weight / bias gradient kernels run on a second stream
         if self.dp is not None:
             self.dp.allreduce_grads(self.optimizer.flat_grads())
         if advance:
