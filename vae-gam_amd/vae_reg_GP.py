@@ -123,6 +123,8 @@ class VAE(nn.Module):
         self.log_maps = False          # per-forward image logging of the reference; opt-in
         self._hrf_cache = {}
         self._gain_const_cache = {}
+        self._gain_streams = {}
+        self.overlap_gains = True      # run the gain algebra on a second stream beside the conv stacks
         self._glm_f32 = None
         self.use_hip_graph = False     # capture the train step into a hipGraph (bench / long runs)
         self._graphs = {}
@@ -319,6 +321,14 @@ class VAE(nn.Module):
             task_var = m * conv + (1 - m) * task_var
         return task_var.float(), gp_kl_loss.float(), beta_mean, beta_cov, post
 
+    def _gains_stream(self, dev):
+        if dev.type != 'cuda' or not self.overlap_gains:
+            return None
+        key = str(dev)
+        if key not in self._gain_streams:
+            self._gain_streams[key] = torch.cuda.Stream(device=dev)
+        return self._gain_streams[key]
+
     def _gain_consts(self, dev):
         key = str(dev)
         if key not in self._gain_const_cache:
@@ -358,6 +368,16 @@ class VAE(nn.Module):
         if noise is None:
             noise = self.draw_noise(Bg, dev)
         eps_w, eps_d = noise['eps_w'][lo:lo + B], noise['eps_d'][lo:lo + B]
+        # The gain algebra is a few hundred tiny fp64 launches that depend only on the covariates and the gain
+        # parameters: it is queued on a second HIP stream beside the encoder/decoder (autograd replays its backward on
+        # that stream too, beside the decoder's backward), and joined where the fused GAM/ELBO kernel needs the gains.
+        gains_stream = self._gains_stream(dev)
+        if gains_stream is not None:
+            gains_stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(gains_stream):
+                gains = self._gains(covariates, noise['eps_beta'])
+        else:
+            gains = self._gains(covariates, noise['eps_beta'])
         mu, u, d = self.encode(x)
         d = d + 1e-6 * (d < 1e-6).any().to(d.dtype)                                        # :321-323 without the sync
         w = u.squeeze(-1)
@@ -368,7 +388,11 @@ class VAE(nn.Module):
         oh = torch.eye(G, device=dev).unsqueeze(1).expand(G, B, G)
         zcat = torch.cat([z.unsqueeze(0).expand(G, B, L), oh], 2).reshape(G * B, L + G)     # :326-329, 339-342
         logits = self._decode_logits(zcat, B).view(G, B, self.img_dim)
-        task_var, gp_kl_loss, beta_mean, beta_cov, post = self._gains(covariates, noise['eps_beta'])
+        task_var, gp_kl_loss, beta_mean, beta_cov, post = gains
+        if gains_stream is not None:
+            torch.cuda.current_stream(dev).wait_stream(gains_stream)
+            for t in (task_var, gp_kl_loss):
+                t.record_stream(torch.cuda.current_stream(dev))
         if W > 1:
             task_var = task_var[:, lo:lo + B].contiguous()                                  # full-batch gains, this rank's columns
         xf = x.reshape(B, self.img_dim)
