@@ -117,6 +117,13 @@ int vg_gam_elbo_bwd(const float* logits, const float* gain, const float* x, cons
                     int32_t C, int32_t B, int64_t V, void* ws,
                     float* d_logits, float* d_gain, double* d_eps, void* stream);
 
+/* Re-pack every conv / transposed-conv weight of the model into the [ci][tap][co] images vg_corr3d / vg_tconv3d_s2 read,
+ * in one launch from the flat fp32 parameter buffer.  segs: device array [nseg][8] of int64
+ * {src offset, dst offset, d0, d1, taps, mode, element count, 0} sorted by dst offset; w is [d0][d1][taps];
+ * mode 0: out[i1][t][i0] = w[i0][i1][t]; mode 1: out[i0][t][i1] = w[i0][i1][t]; mode 2: as 1 with taps reversed
+ * (replaces the permute/flip/contiguous copies that F.conv_transpose3d / autograd do internally). */
+int vg_pack_weights(const float* flat_params, float* packed, const int64_t* segs, int32_t nseg, int64_t total, void* stream);
+
 /* batched lower Cholesky factor of [batch][n][n] float64 SPD matrices (n <= 128), one workgroup per matrix
  * in LDS.  Replaces the Cholesky inside MultivariateNormal(beta_mean, beta_cov + 1e-5 I) (vae_reg_GP.py:368)
  * and MultivariateNormal(qu_m, qu_S) (gp.py:51); unlike hipSOLVER's potrf it can be captured into a hipGraph. */

@@ -44,6 +44,7 @@ _PROTOS = {
     'vg_gam_ws_bytes': (i64, [i32, i32, i64]),
     'vg_gam_elbo_fwd': (ctypes.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, vp]),
     'vg_gam_elbo_bwd': (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, vp]),
+    'vg_pack_weights': (ctypes.c_int, [vp, vp, vp, i32, i64, vp]),
     'vg_cholesky_f64': (ctypes.c_int, [vp, vp, i32, i32, vp]),
     'vg_adam_step': (ctypes.c_int, [vp, vp, vp, vp, i64, i32, f64, f64, f64, vp, vp]),
 }

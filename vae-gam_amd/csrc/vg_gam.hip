@@ -191,7 +191,40 @@ adam_k(T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m, T* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------- weight packing
+// all conv / transposed-conv weights of the model -> the [ci][tap][co] images the conv kernels read through the scalar
+// path (forward and data-gradient variants), in ONE launch straight from the flat parameter buffer
+__global__ void __launch_bounds__(256)
+pack_weights_k(const float* __restrict__ flat, float* __restrict__ packed, const long long* __restrict__ segs, int nseg, long long total) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        int sgi = 0;
+        while (sgi + 1 < nseg && e >= segs[(sgi + 1) * 8 + 1]) ++sgi;            // segments are sorted by destination offset
+        const long long* sg = segs + sgi * 8;
+        const long long src = sg[0], dst = sg[1];
+        const int d0 = (int)sg[2], d1 = (int)sg[3], kvol = (int)sg[4], mode = (int)sg[5];
+        const long long r = e - dst;
+        if (r >= sg[6]) continue;            // alignment gap behind the segment
+        long long si;
+        if (mode == 0) {                     // out[i1][t][i0] = w[i0][i1][t]
+            const int i0 = (int)(r % d0); const long long q = r / d0; const int t = (int)(q % kvol); const int i1 = (int)(q / kvol);
+            si = ((long long)i0 * d1 + i1) * kvol + t;
+        } else {                             // out[i0][t][i1] = w[i0][i1][t or kvol-1-t]
+            const int i1 = (int)(r % d1); const long long q = r / d1; const int t = (int)(q % kvol); const int i0 = (int)(q / kvol);
+            si = ((long long)i0 * d1 + i1) * kvol + (mode == 2 ? kvol - 1 - t : t);
+        }
+        packed[e] = flat[src + si];
+    }
+}
+
 }  // namespace
+
+extern "C" int vg_pack_weights(const float* flat, float* packed, const int64_t* segs, int32_t nseg, int64_t total, void* stream) {
+    if (!flat || !packed || !segs || nseg <= 0 || total <= 0) { vg_set_error("vg_pack_weights: bad arguments"); return VG_ERR_ARG; }
+    long long blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    vg_launch(pack_weights_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, flat, packed, (const long long*)segs, (int)nseg, (long long)total);
+    return vg_check_launch("pack_weights");
+}
 
 extern "C" int64_t vg_gam_ws_bytes(int32_t C, int32_t B, int64_t V) {
     if (C < 0 || C > GMAXC || B <= 0 || V <= 0) return -1;

@@ -42,6 +42,8 @@ class label:
 def _call(t, fn, *args):
     """Launch one C-ABI entry point on t's current stream (optionally bracketed by HIP events)."""
     lib = _lib.get_lib()
+    if not t.is_cuda and not _lib.test_library_injected():
+        raise RuntimeError('refusing to launch %s on a non-GPU tensor: the HIP kernels need device pointers (no CPU path)' % fn)
     if PROFILE is not None and t.is_cuda:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -166,6 +168,43 @@ def pack_weight(w: torch.Tensor, spec: ConvSpec, direction: str) -> torch.Tensor
     if spec.stride == 1:
         w = w.flip(2, 3, 4)
     return w.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def pack_mode(spec: ConvSpec, direction: str) -> int:
+    """vg_pack_weights mode producing the same image as pack_weight(w, spec, direction)."""
+    if (spec.kind == 'conv') == (direction == 'fwd'):
+        return 0
+    return 2 if spec.stride == 1 else 1
+
+
+class PackedWeights:
+    """All packed conv-weight images of a model in one buffer, refreshed by ONE launch per step."""
+
+    def __init__(self, layers, flat, offsets):
+        """layers: [(name, spec, weight Parameter)], flat: the flat fp32 parameter buffer, offsets: {name: element offset}"""
+        segs, views, dst = [], {}, 0
+        for name, spec, w in layers:
+            for direction in ('fwd', 'bwd'):
+                d0, d1 = w.shape[0], w.shape[1]
+                kvol = w[0, 0].numel()
+                n = w.numel()
+                segs.append([offsets[name], dst, d0, d1, kvol, pack_mode(spec, direction), n, 0])
+                views[(name, direction)] = (dst, n, pack_weight(w.detach(), spec, direction).shape)
+                dst += ((n + 3) // 4) * 4
+        self.total = dst
+        self.flat = flat
+        self.buf = torch.empty(dst, dtype=torch.float32, device=flat.device)
+        self.segs = torch.tensor(segs, dtype=torch.int64).to(flat.device)
+        self.nseg = len(segs)
+        self._views = {k: self.buf[o:o + n].view(shape) for k, (o, n, shape) in views.items()}
+        # the kernel walks every destination element, including the alignment gaps: give the last segment the tail
+        self.elems = dst
+
+    def refresh(self):
+        _call(self.flat, 'vg_pack_weights', _p(self.flat), _p(self.buf), _p(self.segs), self.nseg, self.elems)
+
+    def get(self, name, direction):
+        return self._views[(name, direction)]
 
 
 def _conv_desc(N, ci, co, isz, osz, k, stride, pad, relu_in, per_group):
@@ -320,18 +359,20 @@ class BnConvAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, p_in, weight, bias, gamma, beta, spec: ConvSpec, relu_in: bool, per_group: int,
-                input_is_data: bool, sync):
+                input_is_data: bool, sync, packed=None):
         p_in = p_in.contiguous()
         has_bn = gamma is not None
         scale = shift = mean = rstd = None
         with label(spec.name + '/fwd'):
             if has_bn:
                 scale, shift, mean, rstd = bn_stats(p_in, gamma, beta, relu_in, per_group, sync)
-            y = conv_forward(p_in, pack_weight(weight, spec, 'fwd'), bias, spec, relu_in, scale, shift, per_group)
+            wf = packed.get(spec.name, 'fwd') if packed is not None else pack_weight(weight, spec, 'fwd')
+            y = conv_forward(p_in, wf, bias, spec, relu_in, scale, shift, per_group)
         ctx.spec, ctx.relu_in, ctx.per_group, ctx.input_is_data, ctx.sync, ctx.has_bn = \
             spec, relu_in, per_group, input_is_data, sync, has_bn
         ctx.save_for_backward(p_in, weight, gamma, beta, scale, shift, mean, rstd)
         ctx.bias_ref = bias
+        ctx.packed = packed
         return y
 
     @staticmethod
@@ -373,23 +414,23 @@ class BnConvAct(torch.autograd.Function):
                 dbeta = (weight.sum((2, 3, 4)) * db.view(-1, 1)).sum(0)
             else:
                 dw = conv_weight_grad(p_in, dy, spec, relu_in, None, None, per_group, out=wg)
-            return None, dw, db, dgamma, dbeta, None, None, None, None, None
+            return None, dw, db, dgamma, dbeta, None, None, None, None, None, None
         if not overlap:
             dw = conv_weight_grad(p_in, dy, spec, relu_in, scale, shift, per_group, out=wg)
-        wb = pack_weight(weight, spec, 'bwd')
+        wb = ctx.packed.get(spec.name, 'bwd') if ctx.packed is not None else pack_weight(weight, spec, 'bwd')
         in_size = tuple(p_in.shape[2:])
         if ctx.has_bn:
             dp = conv_backward_data(dy, wb, spec, in_size, None)
             dgamma, dbeta = bn_backward_(dp, p_in, gamma, mean, rstd, relu_in, per_group, ctx.sync)
         else:
             dp = conv_backward_data(dy, wb, spec, in_size, p_in if relu_in else None)
-        return dp, dw, db, dgamma, dbeta, None, None, None, None, None
+        return dp, dw, db, dgamma, dbeta, None, None, None, None, None, None
 
 
-def bn_conv_act(p_in, weight, bias, gamma, beta, spec, relu_in, per_group=None, input_is_data=False, sync=None):
+def bn_conv_act(p_in, weight, bias, gamma, beta, spec, relu_in, per_group=None, input_is_data=False, sync=None, packed=None):
     if per_group is None:
         per_group = p_in.shape[0]
-    return BnConvAct.apply(p_in, weight, bias, gamma, beta, spec, relu_in, per_group, input_is_data, sync)
+    return BnConvAct.apply(p_in, weight, bias, gamma, beta, spec, relu_in, per_group, input_is_data, sync, packed)
 
 
 class GamElbo(torch.autograd.Function):

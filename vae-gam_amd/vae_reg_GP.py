@@ -116,6 +116,10 @@ class VAE(nn.Module):
         # everything except the gain sets of covariates beyond num_covariates
         used_gain = {c.name for c in self.schema}
         self.optimizer.used = {i for i, (n, _) in enumerate(named) if self._gain_cov(n) in (None, *used_gain)}
+        g32 = self.optimizer.groups[torch.float32]
+        off32 = {self.optimizer.names[i]: g32['offs'][k] for k, i in enumerate(g32['idx'])}
+        convs = [(sp.name, sp, getattr(self, sp.name).weight) for sp in self.geom.enc + self.geom.dec]
+        self._packed = ops.PackedWeights(convs, g32['p'], {n: off32[n + '.weight'] for n, _, _ in convs})
         self.epoch = 0
         self.loss = {'train': {}, 'test': {}}
         ts = datetime.datetime.now().date()
@@ -204,15 +208,20 @@ class VAE(nn.Module):
         B = x.shape[0]
         h = x.reshape(B, 1, *self.img_shape).contiguous()
         s = self._sync()
-        p = ops.bn_conv_act(h, self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias, e[0], False, B, True, s)
-        p = ops.bn_conv_act(p, self.conv2.weight, self.conv2.bias, None, None, e[1], True, B, False, s)
-        p = ops.bn_conv_act(p, self.conv3.weight, self.conv3.bias, self.bn3.weight, self.bn3.bias, e[2], True, B, False, s)
-        p = ops.bn_conv_act(p, self.conv4.weight, self.conv4.bias, None, None, e[3], True, B, False, s)
-        p = ops.bn_conv_act(p, self.conv5.weight, self.conv5.bias, self.bn5.weight, self.bn5.bias, e[4], True, B, False, s)
+        p = ops.bn_conv_act(h, self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias, e[0], False, B, True, s, self._packed)
+        p = ops.bn_conv_act(p, self.conv2.weight, self.conv2.bias, None, None, e[1], True, B, False, s, self._packed)
+        p = ops.bn_conv_act(p, self.conv3.weight, self.conv3.bias, self.bn3.weight, self.bn3.bias, e[2], True, B, False, s, self._packed)
+        p = ops.bn_conv_act(p, self.conv4.weight, self.conv4.bias, None, None, e[3], True, B, False, s, self._packed)
+        p = ops.bn_conv_act(p, self.conv5.weight, self.conv5.bias, self.bn5.weight, self.bn5.bias, e[4], True, B, False, s, self._packed)
         return p
 
     def encode(self, x):
         """x (B, *img) -> mu (B,L), u (B,L,1), d (B,L)   (vae_reg_GP.py:236-252)."""
+        self._require_gpu(x)
+        self._packed.refresh()
+        return self._encode(x)
+
+    def _encode(self, x):
         p = self._encode_pre(x)
         h = F.relu(p).reshape(p.shape[0], -1)
         h = F.relu(self.fc1(h))
@@ -232,15 +241,17 @@ class VAE(nn.Module):
         h = F.relu(self.fc6(h))
         h = F.relu(self.fc7(h))
         p = self.fc8(h).view(-1, 2 * self.nf, *self.geom.dec_seed)          # ReLU applied by convt1's loader
-        p = ops.bn_conv_act(p, self.convt1.weight, self.convt1.bias, self.bnt1.weight, self.bnt1.bias, dsp[0], True, per_group, False, s)
-        p = ops.bn_conv_act(p, self.convt2.weight, self.convt2.bias, None, None, dsp[1], True, per_group, False, s)
-        p = ops.bn_conv_act(p, self.convt3.weight, self.convt3.bias, self.bnt3.weight, self.bnt3.bias, dsp[2], True, per_group, False, s)
-        p = ops.bn_conv_act(p, self.convt4.weight, self.convt4.bias, None, None, dsp[3], True, per_group, False, s)
-        p = ops.bn_conv_act(p, self.convt5.weight, self.convt5.bias, self.bnt5.weight, self.bnt5.bias, dsp[4], True, per_group, False, s)
+        p = ops.bn_conv_act(p, self.convt1.weight, self.convt1.bias, self.bnt1.weight, self.bnt1.bias, dsp[0], True, per_group, False, s, self._packed)
+        p = ops.bn_conv_act(p, self.convt2.weight, self.convt2.bias, None, None, dsp[1], True, per_group, False, s, self._packed)
+        p = ops.bn_conv_act(p, self.convt3.weight, self.convt3.bias, self.bnt3.weight, self.bnt3.bias, dsp[2], True, per_group, False, s, self._packed)
+        p = ops.bn_conv_act(p, self.convt4.weight, self.convt4.bias, None, None, dsp[3], True, per_group, False, s, self._packed)
+        p = ops.bn_conv_act(p, self.convt5.weight, self.convt5.bias, self.bnt5.weight, self.bnt5.bias, dsp[4], True, per_group, False, s, self._packed)
         return p.reshape(p.shape[0], self.img_dim)
 
     def decode(self, z):
         """z (B, z_dim) -> sigmoid maps (B, V)   (vae_reg_GP.py:254-264)."""
+        self._require_gpu(z)
+        self._packed.refresh()
         return torch.sigmoid(self._decode_logits(z, z.shape[0]))
 
     # ------------------------------------------------------------------ probabilistic pieces
@@ -360,6 +371,8 @@ class VAE(nn.Module):
         dev = x.device
         x = x.float()
         covariates = covariates.float()
+        self._require_gpu(x)                         # before ANY launch: host pointers must never reach a kernel
+        self._packed.refresh()                       # one launch: every conv weight -> the images the kernels read
         # data parallel: this rank holds rows [lo, lo+B) of a global batch of Bg = world*B volumes
         W, lo, Bg = 1, 0, B
         if self.dp is not None:
@@ -378,7 +391,7 @@ class VAE(nn.Module):
                 gains = self._gains(covariates, noise['eps_beta'])
         else:
             gains = self._gains(covariates, noise['eps_beta'])
-        mu, u, d = self.encode(x)
+        mu, u, d = self._encode(x)
         d = d + 1e-6 * (d < 1e-6).any().to(d.dtype)                                        # :321-323 without the sync
         w = u.squeeze(-1)
         z = mu + w * eps_w + d.sqrt() * eps_d                                               # rsample, :325
