@@ -529,9 +529,15 @@ wgrad_plane_k(const float* __restrict__ a, const float* __restrict__ b, const fl
         float bsc = 1.f, bsh = 0.f;
         if (!d.pro_on_a && in_scale && cbl < CB) { bsc = in_scale[g * CB + cbl]; bsh = in_shift[g * CB + cbl]; }
         __syncthreads();                                                  // previous item's tiles fully consumed
-        // ---- DMA of a channel 0 into buffer 0
-        for (int o = wave * VG_WAVE; o < nfl; o += blockDim.x)
-            if (o + lane < nfl) vg_dma4(abase + o + lane, lds + adst + o);
+        // ---- DMA of a channel 0 into buffer 0 (nbuf == CA: the whole item is small enough to keep EVERY channel's
+        //      planes resident -- one DMA phase, no barrier inside the channel loop)
+        const int nres = (p.nbuf == CA) ? CA : 1;
+        for (int c = 0; c < nres; ++c) {
+            const float* src = abase + (size_t)c * d.AD * aplane;
+            float* dst = lds + c * p.a_slot + adst;
+            for (int o = wave * VG_WAVE; o < nfl; o += blockDim.x)
+                if (o + lane < nfl) vg_dma4(src + o + lane, dst + o);
+        }
         for (int phb = 0; phb < p.nph; ++phb) {
             const int ph0 = phb * p.TPH;
             const int nrow = min(p.TPH, d.PH - ph0);                      // valid rows of this block
@@ -583,7 +589,7 @@ wgrad_plane_k(const float* __restrict__ a, const float* __restrict__ b, const fl
                     px += step;
                     while (px >= d.PW) { px -= d.PW; if (++py == p.TPH) { py = 0; ++dz; } }
                 }
-                if (CA > 1) {
+                if (CA > 1 && p.nbuf != CA) {
                     if (p.nbuf == 2) { vg_dma_wait(); __syncthreads(); }
                     else if (ca + 1 < CA) {                               // single buffer: refill after everyone is done reading
                         __syncthreads();
@@ -595,8 +601,8 @@ wgrad_plane_k(const float* __restrict__ a, const float* __restrict__ b, const fl
                     }
                 }
             }
-            if (p.nph > 1 || CA == 1) __syncthreads();                    // tiles are restaged next
-            if (CA > 1 && p.nph > 1 && phb + 1 < p.nph) {                 // channel 0 again for the next row block
+            if (p.nph > 1 || CA == 1 || p.nbuf == CA) __syncthreads();    // tiles are restaged next
+            if (CA > 1 && p.nbuf != CA && p.nph > 1 && phb + 1 < p.nph) { // channel 0 again for the next row block
                 for (int o = wave * VG_WAVE; o < nfl; o += blockDim.x)
                     if (o + lane < nfl) vg_dma4(abase + o + lane, lds + adst + o);
             }
@@ -644,6 +650,13 @@ int launch_plane(const vg_wgrad_desc* d, const float* a, const float* b, const f
     auto slot_for = [&](int LD) { return (((size_t)(LD + 1) * aplane + (size_t)KH * d->AW + 8 * S + 64 + 63) / 64) * 64; };
     auto bch_for = [&](int td, int th) { size_t f = (size_t)td * th * d->PW + 4; while (f % 32 != 2) ++f; return f; };
     int best_td = 0, best_th = 0, best_nbuf = 0;
+    if (CA > 2) {                                   // tiny layers: every channel's planes resident, as many items as possible
+        const size_t small_budget = 48 * 1024;
+        for (int td = 1; td <= 2 && td <= d->PD && !best_td; ++td)
+            if (((size_t)CA * slot_for((td - 1) * S + KD) + d->CB * bch_for(td, d->PH) + 64) * 4 <= small_budget) {
+                best_td = td; best_th = d->PH; best_nbuf = CA;
+            }
+    }
     for (int nbuf = 2; nbuf >= 1 && !best_td; --nbuf) {
         if (nbuf == 2 && CA == 1) continue;
         for (int td = 1; td <= 8 && td <= d->PD; ++td)
