@@ -564,30 +564,46 @@ wgrad_plane_k(const float* __restrict__ a, const float* __restrict__ b, const fl
                 }
                 float sc = 1.f, sh = 0.f;
                 if (d.pro_on_a && in_scale) { sc = in_scale[g * CA + ca]; sh = in_shift[g * CA + ca]; }
+                // UG position groups per iteration: all their LDS operand reads are issued before the first MFMA, so the
+                // LDS latency (~100+ cycles per dependent read) is paid once per UG*TC matrix instructions, not per one
+                constexpr int UG = 4;
                 int px = px0, py = py0, dz = dz0;
-                for (int gi = wave; gi < groups; gi += nwaves) {
-                    const bool pok = dz < p.TPD && pd0 + dz < d.PD && py < nrow;       // this lane's position exists
-                    // b operand: channel cbl at this lane's position (prologue applied; zero for missing positions)
-                    float av = btile[min(cbl, CB - 1) * p.bch + (dz * p.TPH + py) * d.PW + px];   // only CB channel slots exist
-                    av = (pok && cbl < CB) ? fmaf(fmaxf(av, lo_b), bsc, bsh) : 0.f;
-                    const int idb = dz * S, ihb = (ph0 + py) * S - d.pad_h, iwb = px * S - d.pad_w;   // a coords of tap 0 (d relative to ap0)
-                    const float* ap = cur + idb * aplane + ihb * d.AW + iwb;
+                const float* bchan = btile + min(cbl, CB - 1) * p.bch;                   // only CB channel slots exist
+                const bool cb_ok = cbl < CB;
+                for (int gi = wave; gi < groups; gi += nwaves * UG) {
+                    float av[UG], bv[UG][TC]; bool pk[UG], okt[UG][TC];
 #pragma unroll
-                    for (int t = 0; t < TC; ++t) {
-                        float bv;
-                        if (PAD) {
-                            const int id = ap0 + idb + tkd[t], ih = ihb + tkh[t], iw = iwb + tkw[t];
-                            const bool ok = pok && id >= 0 && id < d.AD && ih >= 0 && ih < d.AH && iw >= 0 && iw < d.AW;
-                            bv = ok ? ap[colOff[t]] : 0.f;
-                            if (d.pro_on_a) bv = ok ? fmaf(fmaxf(bv, lo_a), sc, sh) : 0.f;
-                        } else {
-                            bv = pok ? ap[colOff[t]] : 0.f;
-                            if (d.pro_on_a) bv = fmaf(fmaxf(bv, lo_a), sc, sh);
+                    for (int u = 0; u < UG; ++u) {
+                        const bool pok = (gi + u * nwaves < groups) && dz < p.TPD && pd0 + dz < d.PD && py < nrow;
+                        pk[u] = pok;
+                        const int pf = pok ? (dz * p.TPH + py) * d.PW + px : 0;
+                        av[u] = bchan[pf];
+                        const int idb = dz * S, ihb = (ph0 + py) * S - d.pad_h, iwb = px * S - d.pad_w;
+                        const int aoff = idb * aplane + ihb * d.AW + iwb;
+#pragma unroll
+                        for (int t = 0; t < TC; ++t) {
+                            bool ok = pok;
+                            if (PAD) {
+                                const int id = ap0 + idb + tkd[t], ih = ihb + tkh[t], iw = iwb + tkw[t];
+                                ok = pok && id >= 0 && id < d.AD && ih >= 0 && ih < d.AH && iw >= 0 && iw < d.AW;
+                            }
+                            okt[u][t] = ok;
+                            bv[u][t] = cur[ok ? aoff + colOff[t] : 0];
                         }
-                        vg_mfma16(av, bv, acc[ca * TC + t]);
+                        px += step;
+                        while (px >= d.PW) { px -= d.PW; if (++py == p.TPH) { py = 0; ++dz; } }
                     }
-                    px += step;
-                    while (px >= d.PW) { px -= d.PW; if (++py == p.TPH) { py = 0; ++dz; } }
+#pragma unroll
+                    for (int u = 0; u < UG; ++u) {
+                        const float a_ = (pk[u] && cb_ok) ? fmaf(fmaxf(av[u], lo_b), bsc, bsh) : 0.f;
+#pragma unroll
+                        for (int t = 0; t < TC; ++t) {
+                            float b_ = bv[u][t];
+                            if (d.pro_on_a) b_ = fmaf(fmaxf(b_, lo_a), sc, sh);
+                            b_ = okt[u][t] ? b_ : 0.f;
+                            vg_mfma16(a_, b_, acc[ca * TC + t]);
+                        }
+                    }
                 }
                 if (CA > 1 && p.nbuf != CA) {
                     if (p.nbuf == 2) { vg_dma_wait(); __syncthreads(); }
