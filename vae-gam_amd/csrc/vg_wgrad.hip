@@ -675,8 +675,15 @@ int launch_plane(const vg_wgrad_desc* d, const float* a, const float* b, const f
     }
     for (int nbuf = 2; nbuf >= 1 && !best_td; --nbuf) {
         if (nbuf == 2 && CA == 1) continue;
+        // smallest tile that fits: LDS per block decides how many blocks (each with its own DMA in flight) share a CU
+        // but at least ~128 positions (32 MFMA position groups) per tile, or the barriers outweigh the matrix work
+        int td_want = vg_cdiv(128, d->PH * d->PW);
+        if (td_want > d->PD) td_want = d->PD;
         for (int td = 1; td <= 8 && td <= d->PD; ++td)
-            if ((nbuf * slot_for((td - 1) * S + KD) + d->CB * bch_for(td, d->PH) + 64) * 4 <= budget) { best_td = td; best_th = d->PH; best_nbuf = nbuf; }
+            if ((nbuf * slot_for((td - 1) * S + KD) + d->CB * bch_for(td, d->PH) + 64) * 4 <= budget) {
+                best_td = td; best_th = d->PH; best_nbuf = nbuf;
+                if (td >= td_want) break;
+            }
     }
     if (!best_td)                                   // row blocks of one position plane, single a buffer
         for (int th = d->PH; th >= 4; --th)
@@ -692,7 +699,7 @@ int launch_plane(const vg_wgrad_desc* d, const float* a, const float* b, const f
     p.lds_floats = (int)fl;
     p.pdblocks = vg_cdiv(d->PD, p.TPD);
     p.items = d->N * p.pdblocks;
-    const int grid = p.items < 768 ? p.items : 768;
+    const int grid = p.items < 1536 ? p.items : 1536;
     const int len = d->CB * CA * KVOL;
     if (ws_bytes_only) { *ws_bytes_only = (int64_t)grid * len * sizeof(float); return VG_OK; }
     vg_launch(wgrad_plane_k<CA, TC, KD, KH, KW, S, PAD>, dim3(grid), dim3(256), fl * sizeof(float), s, a, b, in_scale, in_shift, ws, p);
