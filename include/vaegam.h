@@ -117,6 +117,30 @@ int vg_gam_elbo_bwd(const float* logits, const float* gain, const float* x, cons
                     int32_t C, int32_t B, int64_t V, void* ws,
                     float* d_logits, float* d_gain, double* d_eps, void* stream);
 
+/* Batch-norm parameter gradients from vg_bn_bwd_reduce's per-(group, channel) sums:
+ *   dgamma[c] (+)= sum_g sums[g][c][1],  dbeta[c] (+)= sum_g sums[g][c][0]   (accumulate != 0 adds into the .grad buffers;
+ *   replaces autograd's sum + add launches after torch.nn.BatchNorm3d's backward, vae_reg_GP.py:195-201,216-222). */
+int vg_bn_param_grad(const double* sums, int32_t G, int32_t C, float* dgamma, float* dbeta, int32_t accumulate, void* stream);
+
+/* Latent sample + KL of the low-rank Gaussian posterior in one launch (vae_reg_GP.py:321-329, 339-342, 400):
+ *   d = exp(a) + 1e-6*[any(exp(a) < 1e-6)],  z = mu + w*eps_w + sqrt(d)*eps_d,
+ *   kl[b] = 0.5*(-log(1 + sum w^2/d) - sum log d + sum d + sum w^2 + sum mu^2 - L),
+ *   zcat[g*B + b] = [z[b], onehot_G(g)]  (the C+1 decoder inputs, row-major (G*B, L+G)).
+ * mu, w, a, eps_d: [B][L]; eps_w: [B]; d_out: [B][L]; flag_out: [1] (the floor that was applied, 0 or 1e-6). */
+int vg_latent_fwd(const float* mu, const float* w, const float* a, const float* eps_w, const float* eps_d,
+                  int32_t B, int32_t L, int32_t G, float* zcat, float* kl, float* d_out, float* flag_out, void* stream);
+/* backward of the above: g_zcat [G*B][L+G] (may be NULL), g_kl [B] (may be NULL) -> g_mu, g_w, g_a [B][L]. */
+int vg_latent_bwd(const float* mu, const float* w, const float* d, const float* flag, const float* eps_w, const float* eps_d,
+                  const float* g_zcat, const float* g_kl, int32_t B, int32_t L, int32_t G,
+                  float* g_mu, float* g_w, float* g_a, void* stream);
+
+/* ELBO assembly (vae_reg_GP.py:406-410): loss[0] = c_kl*sum kl[B] + c_slp*sum slp[B] + c_gp*gp_kl[0] + c_dist*sum dist[CB];
+ * backward writes the four constant gradients scaled by g_loss[0]. */
+int vg_loss_fwd(const float* kl, const float* slp, const float* dist, const float* gp_kl, int32_t B, int32_t CB,
+                double c_kl, double c_slp, double c_gp, double c_dist, float* loss, void* stream);
+int vg_loss_bwd(const float* g_loss, int32_t B, int32_t CB, double c_kl, double c_slp, double c_gp, double c_dist,
+                float* g_kl, float* g_slp, float* g_dist, float* g_gp, void* stream);
+
 /* Re-pack every conv / transposed-conv weight of the model into the [ci][tap][co] images vg_corr3d / vg_tconv3d_s2 read,
  * in one launch from the flat fp32 parameter buffer.  segs: device array [nseg][8] of int64
  * {src offset, dst offset, d0, d1, taps, mode, element count, 0} sorted by dst offset; w is [d0][d1][taps];

@@ -118,6 +118,82 @@ def run_gam_case(dev, C, B, V, seed=0):
     np.testing.assert_allclose(maps[C + 1].cpu().numpy(), full.numpy(), atol=1e-5)
 
 
+def ref_latent(mu, w, a, eps_w, eps_d, G):
+    """The reference's operator sequence (vae_reg_GP.py:321-329, 339-342, 400) through its own distribution classes."""
+    B, L = mu.shape
+    d = torch.exp(a)
+    if (d < 1e-6).any():
+        d = d + 1e-6
+    q = torch.distributions.LowRankMultivariateNormal(mu, w.unsqueeze(-1), d)
+    z = mu + w * eps_w.view(B, 1) + d.sqrt() * eps_d            # rsample with the given draws
+    p = torch.distributions.MultivariateNormal(torch.zeros(L), torch.eye(L))
+    kl = torch.distributions.kl_divergence(q, p)
+    oh = torch.eye(G).unsqueeze(1).expand(G, B, G)
+    zcat = torch.cat([z.unsqueeze(0).expand(G, B, L), oh], 2).reshape(G * B, L + G)
+    return zcat, kl, d
+
+
+def run_latent_case(dev, B, L, G, seed=0, tiny_d=False):
+    g = torch.Generator().manual_seed(seed)
+    mu = torch.randn(B, L, generator=g); w = 0.5 * torch.randn(B, L, generator=g); a = 0.7 * torch.randn(B, L, generator=g) - 0.5
+    if tiny_d:
+        a[B // 2, L // 3] = -15.0                                 # exp(a) < 1e-6: the batch-wide floor kicks in
+    eps_w = torch.randn(B, 1, generator=g); eps_d = torch.randn(B, L, generator=g)
+    gz = torch.randn(G * B, L + G, generator=g); gk = torch.randn(B, generator=g)
+    rv = [t.clone().requires_grad_(True) for t in (mu, w, a)]
+    zc_r, kl_r, d_r = ref_latent(*rv, eps_w, eps_d, G)
+    gr = torch.autograd.grad((zc_r * gz).sum() + (kl_r * gk).sum(), rv)
+    dv = [t.to(dev).clone().requires_grad_(True) for t in (mu, w, a)]
+    zc, kl, d = ops.LatentSample.apply(*dv, eps_w.to(dev), eps_d.to(dev), G)
+    np.testing.assert_allclose(zc.detach().cpu().numpy(), zc_r.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(kl.detach().cpu().numpy(), kl_r.detach().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(d.cpu().numpy(), d_r.detach().numpy(), rtol=1e-6, atol=0)
+    gd = torch.autograd.grad((zc * gz.to(dev)).sum() + (kl * gk.to(dev)).sum(), dv)
+    for x_, y_, nm in zip(gd, gr, ('g_mu', 'g_w', 'g_a')):
+        np.testing.assert_allclose(x_.cpu().numpy(), y_.numpy(), rtol=2e-4, atol=2e-5, err_msg=nm)
+
+
+def run_loss_case(dev, B, C, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    kl = torch.rand(B, generator=g) * 30; slp = -1e4 * torch.rand(B, generator=g); dist = torch.rand(C, B, generator=g) * 50
+    gp = torch.rand(1, generator=g) * 100
+    coef = (1.0 / B, -1.0 / B, 0.37, 1e-3 * B)
+    rv = [t.clone().requires_grad_(True) for t in (kl, slp, dist, gp)]
+    loss_r = -((-rv[0] + rv[1]).sum(0) / B) + coef[2] * rv[3] + 1e-3 * (B * rv[2].sum())       # vae_reg_GP.py:388-389, 406-410
+    gr = torch.autograd.grad(loss_r.sum(), rv)
+    dv = [t.to(dev).clone().requires_grad_(True) for t in (kl, slp, dist, gp)]
+    loss = ops.ElboLoss.apply(*dv, coef)
+    assert loss.shape == (1,)
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), loss_r.detach().numpy(), rtol=1e-5)
+    gd = torch.autograd.grad(loss.sum(), dv)
+    for x_, y_ in zip(gd, gr):
+        np.testing.assert_allclose(x_.cpu().numpy(), y_.numpy(), rtol=1e-6, atol=0)
+
+
+def run_linear_case(dev, B=24, fin=40, fout=17, seed=0):
+    """LinearAct with direct accumulation into existing .grad buffers == nn.Linear + relu under autograd."""
+    g = torch.Generator().manual_seed(seed)
+    ref = torch.nn.Linear(fin, fout); lay = torch.nn.Linear(fin, fout).to(dev)
+    with torch.no_grad():
+        lay.weight.copy_(ref.weight); lay.bias.copy_(ref.bias)
+    x = torch.randn(B, fin, generator=g); gy = torch.randn(B, fout, generator=g)
+    for relu in (True, False):
+        xr = x.clone().requires_grad_(True)
+        yr = ref(xr); yr = torch.relu(yr) if relu else yr
+        ref.zero_grad(); (yr * gy).sum().backward()
+        for prefilled in (False, True):
+            xd = x.to(dev).clone().requires_grad_(True)
+            lay.weight.grad = torch.ones_like(lay.weight) if prefilled else None
+            lay.bias.grad = torch.ones_like(lay.bias) if prefilled else None
+            y = ops.linear_act(lay, xd, relu)
+            (y * gy.to(dev)).sum().backward()
+            off = 1.0 if prefilled else 0.0
+            np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(lay.weight.grad.cpu().numpy() - off, ref.weight.grad.numpy(), rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(lay.bias.grad.cpu().numpy() - off, ref.bias.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
 def run_adam_case(dev, dtype, n=5000, steps=3, seed=0):
     g = torch.Generator().manual_seed(seed)
     p0 = torch.randn(n, generator=g, dtype=dtype)

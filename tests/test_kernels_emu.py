@@ -47,6 +47,20 @@ def test_gam_elbo():
     K.run_gam_case('cpu', C=3, B=3, V=1500)
 
 
+def test_latent_sample_kl():
+    K.run_latent_case('cpu', B=5, L=32, G=4)
+    K.run_latent_case('cpu', B=7, L=70, G=2, seed=3, tiny_d=True)
+
+
+def test_elbo_loss():
+    K.run_loss_case('cpu', B=32, C=3)
+    K.run_loss_case('cpu', B=300, C=8, seed=1)
+
+
+def test_linear_act_accumulates_into_grad():
+    K.run_linear_case('cpu')
+
+
 def test_gam_elbo_no_covariates():
     K.run_gam_case('cpu', C=0, B=2, V=700, seed=2)
 

@@ -53,6 +53,21 @@ def test_gam_elbo():
     K.run_gam_case('cuda', C=8, B=4, V=70315, seed=4)
 
 
+def test_latent_sample_kl():
+    K.run_latent_case('cuda', B=5, L=32, G=4)
+    K.run_latent_case('cuda', B=7, L=70, G=2, seed=3, tiny_d=True)
+    K.run_latent_case('cuda', B=64, L=32, G=9, seed=5)
+
+
+def test_elbo_loss():
+    K.run_loss_case('cuda', B=32, C=3)
+    K.run_loss_case('cuda', B=300, C=8, seed=1)
+
+
+def test_linear_act_accumulates_into_grad():
+    K.run_linear_case('cuda')
+
+
 def test_gam_elbo_no_covariates():
     K.run_gam_case('cuda', C=0, B=2, V=700, seed=2)
 

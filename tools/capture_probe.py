@@ -44,3 +44,18 @@ def fb():
     m.optimizer.zero_grad(); l = m.forward(ids, cov, x, 'train', noise=noise); l.backward()
 probe('fwd+bwd', fb)
 probe('adam', lambda: m.optimizer.apply_update())
+W = torch.randn(17, 40, device='cuda'); Wg = torch.zeros_like(W); bgr = torch.zeros(17, device='cuda')
+gy = torch.randn(96, 17, device='cuda'); xx = torch.randn(96, 40, device='cuda'); one = torch.ones(96, device='cuda')
+probe('addmm_', lambda: Wg.addmm_(gy.t(), xx))
+probe('addmv_', lambda: bgr.addmv_(gy.t(), one))
+probe('threshold_backward', lambda: torch.ops.aten.threshold_backward(gy, gy, 0.0))
+mu = torch.randn(32, 32, device='cuda'); ew = torch.randn(32, 1, device='cuda')
+probe('latent', lambda: ops.LatentSample.apply(mu, mu, mu, ew, mu, 4))
+kl = torch.randn(32, device='cuda'); dist = torch.randn(3, 32, device='cuda'); gp_ = torch.randn(1, device='cuda')
+probe('loss', lambda: ops.ElboLoss.apply(kl, kl, dist, gp_, (1.0, 2.0, 3.0, 4.0)))
+zc = torch.randn(128, 36, device='cuda')
+probe('decode', lambda: m._decode_logits(zc, 32))
+def core_nograd():
+    with torch.no_grad():
+        m.forward_core(cov, x, noise)
+probe('forward_core nograd', core_nograd)

@@ -5,7 +5,7 @@ import collections, csv, glob, json, re, sys
 def short(n): return re.sub(r'\(anonymous namespace\)::', '', n)
 
 tag = sys.argv[1] if len(sys.argv) > 1 else 'round1'
-rows = list(csv.DictReader(open(glob.glob('gpurun_out/r1prof/runc/*_kernel_stats.csv')[0])))
+rows = list(csv.DictReader(open(glob.glob('gpurun_out/r1prof/runc*kernel_stats.csv')[0])))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 with open('profiles/%s_kernel_stats.csv' % tag, 'w') as f:
     f.write('# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline   (MI355X, batch 32, 3 covariates;\n')
@@ -17,7 +17,7 @@ with open('profiles/%s_kernel_stats.csv' % tag, 'w') as f:
 # per-dispatch traffic, grouped by (kernel, grid size) so that layers sharing a kernel instance stay apart
 traffic = collections.defaultdict(dict)
 for name, ctr in (('r1fetch', 'FETCH_SIZE'), ('r1write', 'WRITE_SIZE')):
-    for r in csv.DictReader(open(glob.glob('gpurun_out/%s/runc/*_counter_collection.csv' % name)[0])):
+    for r in csv.DictReader(open(glob.glob('gpurun_out/%s/runc*counter_collection.csv' % name)[0])):
         if r['Counter_Name'] == ctr:
             traffic[(short(r['Kernel_Name'])[:120], r['Grid_Size'])].setdefault(ctr, []).append(float(r['Counter_Value']))
 out = {}
@@ -31,7 +31,7 @@ for (k, grid), v in traffic.items():
 json.dump(out, open('profiles/%s_hbm_traffic.json' % tag, 'w'), indent=1, sort_keys=True)
 for k in sorted(out, key=lambda k: -out[k]['hbm_bytes_per_launch'])[:10]:
     print('%-95s fetch(raw) %7.1f MB write %7.1f MB' % (k[:95], out[k]['fetch_bytes_raw'] / 1e6, out[k]['write_bytes'] / 1e6))
-tr = list(csv.DictReader(open(glob.glob('gpurun_out/r1prof/runc/*_kernel_trace.csv')[0])))
+tr = list(csv.DictReader(open(glob.glob('gpurun_out/r1prof/runc*kernel_trace.csv')[0])))
 print('dispatches in trace', len(tr))
 
 # traffic keyed the way bench.py names its kernels (entry point : layer / direction), for roofline.traffic

@@ -251,3 +251,24 @@ extern "C" int vg_channel_sum(const float* x, int32_t N, int32_t C, int64_t P, v
     vg_launch(chsum_fold_k, dim3(C), dim3(64), 0, s, (const double*)part, (int)C, chunks, (int)accumulate, out);
     return vg_check_launch("channel_sum fold");
 }
+
+namespace {
+// dgamma[c] (+)= sum_g sums[g][c][1], dbeta[c] (+)= sum_g sums[g][c][0]
+__global__ void __launch_bounds__(64)
+bn_param_grad_k(const double* __restrict__ sums, int G, int C, int accumulate, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0, b = 0;
+    for (int g = 0; g < G; ++g) { b += sums[((size_t)g * C + c) * 2]; a += sums[((size_t)g * C + c) * 2 + 1]; }
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)a;
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)b;
+}
+}  // namespace
+
+extern "C" int vg_bn_param_grad(const double* sums, int32_t G, int32_t C, float* dgamma, float* dbeta, int32_t accumulate,
+                                void* stream) {
+    if (!sums || !dgamma || !dbeta || G <= 0 || C <= 0) { vg_set_error("vg_bn_param_grad: bad argument"); return VG_ERR_ARG; }
+    vg_launch(bn_param_grad_k, dim3(vg_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, sums, (int)G, (int)C, (int)accumulate, dgamma,
+              dbeta);
+    return vg_check_launch("bn_param_grad");
+}

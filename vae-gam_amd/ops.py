@@ -307,9 +307,17 @@ def bn_stats(x, gamma, beta, relu, per_group, sync=None):
     return out[0], out[1], out[2], out[3]
 
 
-def bn_backward_(dxe, p, gamma, mean, rstd, relu, per_group, sync=None):
+def _grad_buf(t):
+    """The parameter's contiguous fp32 .grad (a view of the flat gradient buffer) if it exists, else None."""
+    if isinstance(t, torch.nn.Parameter) and t.grad is not None and t.grad.is_contiguous() and t.grad.dtype == torch.float32:
+        return t.grad
+    return None
+
+
+def bn_backward_(dxe, p, gamma, mean, rstd, relu, per_group, sync=None, beta=None):
     """In place: dxe (grad w.r.t. the normalised tensor) -> grad w.r.t. the stored pre-activation p.
-    Returns (dgamma[C], dbeta[C]) summed over groups."""
+    Returns (dgamma[C], dbeta[C]) summed over groups -- or (None, None) after adding them straight into
+    gamma.grad / beta.grad when both exist (one launch instead of autograd's two sums + two adds)."""
     lib = _lib.get_lib()
     N, C = p.shape[0], p.shape[1]
     P = p[0, 0].numel()
@@ -327,10 +335,14 @@ def bn_backward_(dxe, p, gamma, mean, rstd, relu, per_group, sync=None):
     parts = torch.empty((2, G, C), dtype=torch.float32, device=p.device)
     _call(p, 'vg_bn_bwd_apply', _p(dxe), _p(p), N, C, P, per_group, int(relu), _p(gamma), _p(mean), _p(rstd), _p(sums),
              count, _p(parts[0]), _p(parts[1]))
-    if local is not None:
-        loc = local.view(G, C, 2).sum(0).float()
-        return loc[:, 1].contiguous(), loc[:, 0].contiguous()
-    return parts[0].sum(0), parts[1].sum(0)
+    src = local if local is not None else sums      # data parallel: this rank's share (the gradient all-reduce sums them)
+    gg, bg = _grad_buf(gamma), _grad_buf(beta)
+    if gg is not None and bg is not None:
+        _call(p, 'vg_bn_param_grad', _p(src), G, C, _p(gg), _p(bg), 1)
+        return None, None
+    dg = torch.empty(C, dtype=torch.float32, device=p.device); db = torch.empty_like(dg)
+    _call(p, 'vg_bn_param_grad', _p(src), G, C, _p(dg), _p(db), 0)
+    return dg, db
 
 
 def channel_sum(x, out=None):
@@ -421,7 +433,7 @@ class BnConvAct(torch.autograd.Function):
         in_size = tuple(p_in.shape[2:])
         if ctx.has_bn:
             dp = conv_backward_data(dy, wb, spec, in_size, None)
-            dgamma, dbeta = bn_backward_(dp, p_in, gamma, mean, rstd, relu_in, per_group, ctx.sync)
+            dgamma, dbeta = bn_backward_(dp, p_in, gamma, mean, rstd, relu_in, per_group, ctx.sync, beta)
         else:
             dp = conv_backward_data(dy, wb, spec, in_size, p_in if relu_in else None)
         return dp, dw, db, dgamma, dbeta, None, None, None, None, None, None
@@ -465,6 +477,109 @@ class GamElbo(torch.autograd.Function):
         _call(x, 'vg_gam_elbo_bwd', _p(logits), _p(gain), _p(x), _p(eps), _p(glm), _p(dist), _p(g_slp), _p(g_dist),
                  C, B, V, _p(ws), _p(d_logits), _p(d_gain), _p(d_eps))
         return d_logits, d_gain, None, d_eps, None
+
+
+class LatentSample(torch.autograd.Function):
+    """(mu, w, a, eps_w, eps_d, G) -> (zcat[G*B, L+G], kl_z[B], d[B, L]); one launch each way
+    (vae_reg_GP.py:321-329, 339-342, 400).  `a` is fc43's output (d = exp(a) + the batch-wide 1e-6 floor)."""
+
+    @staticmethod
+    def forward(ctx, mu, w, a, eps_w, eps_d, G):
+        B, L = mu.shape
+        mu = _chk(mu.contiguous()); w = _chk(w.contiguous()); a = _chk(a.contiguous())
+        eps_w = _chk(eps_w.contiguous()); eps_d = _chk(eps_d.contiguous())
+        assert w.shape == (B, L) and a.shape == (B, L) and eps_d.shape == (B, L) and eps_w.numel() == B
+        zcat = torch.empty((G * B, L + G), dtype=torch.float32, device=mu.device)
+        kl = torch.empty(B, dtype=torch.float32, device=mu.device)
+        d = torch.empty((B, L), dtype=torch.float32, device=mu.device)
+        flag = torch.empty(1, dtype=torch.float32, device=mu.device)
+        _call(mu, 'vg_latent_fwd', _p(mu), _p(w), _p(a), _p(eps_w), _p(eps_d), B, L, G, _p(zcat), _p(kl), _p(d), _p(flag))
+        ctx.save_for_backward(mu, w, d, flag, eps_w, eps_d)
+        ctx.G = G
+        ctx.mark_non_differentiable(d)
+        return zcat, kl, d
+
+    @staticmethod
+    def backward(ctx, g_zcat, g_kl, _g_d):
+        mu, w, d, flag, eps_w, eps_d = ctx.saved_tensors
+        B, L = mu.shape
+        g_mu = torch.empty_like(mu); g_w = torch.empty_like(mu); g_a = torch.empty_like(mu)
+        gz = _p(_chk(g_zcat.contiguous())) if g_zcat is not None else None
+        gk = _p(_chk(g_kl.contiguous())) if g_kl is not None else None
+        _call(mu, 'vg_latent_bwd', _p(mu), _p(w), _p(d), _p(flag), _p(eps_w), _p(eps_d), gz, gk, B, L, ctx.G,
+                 _p(g_mu), _p(g_w), _p(g_a))
+        return g_mu, g_w, g_a, None, None, None
+
+
+class ElboLoss(torch.autograd.Function):
+    """loss[1] = c_kl*sum(kl_z) + c_slp*sum(slp) + c_gp*gp_kl + c_dist*sum(dist)   (vae_reg_GP.py:406-410)."""
+
+    @staticmethod
+    def forward(ctx, kl_z, slp, dist, gp_kl, coef):
+        kl_z = _chk(kl_z.contiguous()); slp = _chk(slp.contiguous()); dist = _chk(dist.contiguous()); gp_kl = _chk(gp_kl.contiguous())
+        loss = torch.empty(1, dtype=torch.float32, device=kl_z.device)
+        ctx.coef = tuple(float(c) for c in coef)
+        ctx.shapes = (kl_z.shape, slp.shape, dist.shape, gp_kl.shape)
+        _call(kl_z, 'vg_loss_fwd', _p(kl_z), _p(slp), _p(dist), _p(gp_kl), kl_z.numel(), dist.numel(), *ctx.coef, _p(loss))
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        sk, ss, sd, sg = ctx.shapes
+        g = _chk(g.contiguous())
+        g_kl = torch.empty(sk, dtype=torch.float32, device=g.device); g_slp = torch.empty(ss, dtype=torch.float32, device=g.device)
+        g_dist = torch.empty(sd, dtype=torch.float32, device=g.device); g_gp = torch.empty(sg, dtype=torch.float32, device=g.device)
+        _call(g, 'vg_loss_bwd', _p(g), g_kl.numel(), g_dist.numel(), *ctx.coef, _p(g_kl), _p(g_slp), _p(g_dist), _p(g_gp))
+        return g_kl, g_slp, g_dist, g_gp, None
+
+
+class LinearAct(torch.autograd.Function):
+    """y = [relu](x @ W^T + b) for the fully connected layers (vae_reg_GP.py:203-209, 224-234): the GEMMs stay in
+    hipBLASLt (plain library GEMMs), but the backward adds dW / db straight into the .grad views of the flat gradient
+    buffer (GEMM / GEMV with beta = 1) instead of autograd's separate reduce + accumulate launches."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        y = torch.addmm(bias, x, weight.t())
+        if relu:
+            y = torch.relu_(y)
+        ctx.relu = relu
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.bias_ref = bias
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        bias = ctx.bias_ref
+        if ctx.relu:
+            gy = torch.ops.aten.threshold_backward(gy, y, 0.0)
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        wg, bg = _grad_buf(weight), _grad_buf(bias)
+        gw = gb = None
+        if wg is not None:
+            wg.addmm_(gy.t(), x)
+        else:
+            gw = gy.t() @ x
+        if bg is not None:
+            bg.addmv_(gy.t(), _ones(gy.shape[0], gy.device))
+        else:
+            gb = gy.sum(0)
+        return gx, gw, gb, None
+
+
+_ONES = {}
+
+
+def _ones(n, device):
+    key = (n, str(device))
+    if key not in _ONES:
+        _ONES[key] = torch.ones(n, dtype=torch.float32, device=device)
+    return _ONES[key]
+
+
+def linear_act(layer, x, relu):
+    return LinearAct.apply(x, layer.weight, layer.bias, relu)
 
 
 def gam_maps(logits, gain, x, eps, glm):

@@ -89,6 +89,7 @@ class VAE(nn.Module):
         self.glm_reg_scale = glm_reg_scale
         self.inducing_pts = num_inducing_pts
         self.gp_kl_scale = torch.as_tensor((gp_kl_scale)).to(self.device)
+        self._gp_kl_scale_host = float(gp_kl_scale)          # the fused ELBO kernel takes it by value (no device read-back)
         self.max_ls = torch.as_tensor(3.0).to(self.device)
         if xu_ranges is None:
             xu_ranges = utils.get_xu_ranges(csv_files)
@@ -221,15 +222,21 @@ class VAE(nn.Module):
         self._packed.refresh()
         return self._encode(x)
 
-    def _encode(self, x):
+    def _encode_heads(self, x):
+        """-> mu (B,L), w (B,L), a (B,L) with u = w[..., None], d = exp(a)."""
         p = self._encode_pre(x)
+        la = ops.linear_act
         h = F.relu(p).reshape(p.shape[0], -1)
-        h = F.relu(self.fc1(h))
-        h = F.relu(self.fc2(h))
-        mu = self.fc41(F.relu(self.fc31(h)))
-        u = self.fc42(F.relu(self.fc32(h))).unsqueeze(-1)
-        d = torch.exp(self.fc43(F.relu(self.fc33(h))))
-        return mu, u, d
+        h = la(self.fc1, h, True)
+        h = la(self.fc2, h, True)
+        mu = la(self.fc41, la(self.fc31, h, True), False)
+        w = la(self.fc42, la(self.fc32, h, True), False)
+        a = la(self.fc43, la(self.fc33, h, True), False)
+        return mu, w, a
+
+    def _encode(self, x):
+        mu, w, a = self._encode_heads(x)
+        return mu, w.unsqueeze(-1), torch.exp(a)
 
     def _decode_logits(self, z, per_group):
         """z (N, z_dim), N = groups*per_group -> pre-sigmoid maps (N, V).  Batch-norm statistics are
@@ -237,10 +244,9 @@ class VAE(nn.Module):
         self._require_gpu(z)
         dsp = self.geom.dec
         s = self._sync()
-        h = F.relu(self.fc5(z))
-        h = F.relu(self.fc6(h))
-        h = F.relu(self.fc7(h))
-        p = self.fc8(h).view(-1, 2 * self.nf, *self.geom.dec_seed)          # ReLU applied by convt1's loader
+        la = ops.linear_act
+        h = la(self.fc7, la(self.fc6, la(self.fc5, z, True), True), True)
+        p = la(self.fc8, h, False).view(-1, 2 * self.nf, *self.geom.dec_seed)   # ReLU applied by convt1's loader
         p = ops.bn_conv_act(p, self.convt1.weight, self.convt1.bias, self.bnt1.weight, self.bnt1.bias, dsp[0], True, per_group, False, s, self._packed)
         p = ops.bn_conv_act(p, self.convt2.weight, self.convt2.bias, None, None, dsp[1], True, per_group, False, s, self._packed)
         p = ops.bn_conv_act(p, self.convt3.weight, self.convt3.bias, self.bnt3.weight, self.bnt3.bias, dsp[2], True, per_group, False, s, self._packed)
@@ -366,7 +372,7 @@ class VAE(nn.Module):
     def forward_core(self, covariates, x, noise=None, want_maps=False):
         """The arithmetic of VAE.forward (vae_reg_GP.py:307-410), on device, no host syncs.
         Returns a dict of device tensors: loss (1,), z, mu, u, d, kl_z, task_var (C,B), gp_kl_loss,
-        glm_reg, sum_log_prob, logits (C+1,B,V) and, if asked, maps (C+2,B,V)."""
+        dist (C,B; glm_reg = global batch * dist.sum()), sum_log_prob, logits (C+1,B,V) and, if asked, maps (C+2,B,V)."""
         B, C, L = x.shape[0], self.num_covariates, self.num_latents
         dev = x.device
         x = x.float()
@@ -391,15 +397,12 @@ class VAE(nn.Module):
                 gains = self._gains(covariates, noise['eps_beta'])
         else:
             gains = self._gains(covariates, noise['eps_beta'])
-        mu, u, d = self._encode(x)
-        d = d + 1e-6 * (d < 1e-6).any().to(d.dtype)                                        # :321-323 without the sync
-        w = u.squeeze(-1)
-        z = mu + w * eps_w + d.sqrt() * eps_d                                               # rsample, :325
-        cap = 1.0 + (w * w / d).sum(-1)
-        kl_z = 0.5 * (-(cap.log() + d.log().sum(-1)) + d.sum(-1) + (w * w).sum(-1) + (mu * mu).sum(-1) - L)   # :400
+        mu, w, a = self._encode_heads(x)
         G = C + 1
-        oh = torch.eye(G, device=dev).unsqueeze(1).expand(G, B, G)
-        zcat = torch.cat([z.unsqueeze(0).expand(G, B, L), oh], 2).reshape(G * B, L + G)     # :326-329, 339-342
+        # d = exp(a) + 1e-6*[any(d < 1e-6)] (:321-323, no sync), z = rsample (:325), kl_z (:400) and the G decoder
+        # inputs [z, onehot] (:326-329, 339-342) in ONE launch (and one for the backward)
+        zcat, kl_z, d = ops.LatentSample.apply(mu, w, a, eps_w, eps_d, G)
+        z, u = zcat[:B, :L], w.unsqueeze(-1)
         logits = self._decode_logits(zcat, B).view(G, B, self.img_dim)
         task_var, gp_kl_loss, beta_mean, beta_cov, post = gains
         if gains_stream is not None:
@@ -410,12 +413,13 @@ class VAE(nn.Module):
             task_var = task_var[:, lo:lo + B].contiguous()                                  # full-batch gains, this rank's columns
         xf = x.reshape(B, self.img_dim)
         slp, dist = ops.GamElbo.apply(logits, task_var, xf, self.epsilon.view(-1), self._glm())
-        glm_reg = Bg * dist.sum()                                                           # :388-389 (cdist's factor = global batch)
-        elbo = (-kl_z + slp).sum(0) / Bg                                                    # :406-408 (mean over the global batch)
-        # replicated terms are divided by the world size: the gradient all-reduce SUMS the per-rank losses
-        loss = -elbo + self.gp_kl_scale * gp_kl_loss / W + self.glm_reg_scale * glm_reg     # :410
+        # glm_reg = Bg * sum(dist) (:388-389, cdist's factor = global batch); elbo = sum(-kl_z + slp) / Bg (:406-408);
+        # loss = -elbo + gp_kl_scale * gp_kl + glm_reg_scale * glm_reg (:410) -- one launch.  Replicated terms are
+        # divided by the world size: the gradient all-reduce SUMS the per-rank losses.
+        loss = ops.ElboLoss.apply(kl_z, slp, dist, gp_kl_loss,
+                                  (1.0 / Bg, -1.0 / Bg, self._gp_kl_scale_host / W, float(self.glm_reg_scale) * Bg))
         out = dict(loss=loss, z=z, mu=mu, u=u, d=d, kl_z=kl_z, task_var=task_var, gp_kl_loss=gp_kl_loss,
-                   glm_reg=glm_reg, sum_log_prob=slp, dist=dist, logits=logits, beta_mean=beta_mean, beta_cov=beta_cov,
+                   sum_log_prob=slp, dist=dist, logits=logits, beta_mean=beta_mean, beta_cov=beta_cov,
                    gp_post=post)
         if want_maps:
             out['maps'] = ops.gam_maps(logits.detach(), task_var.detach(), xf, self.epsilon.detach().view(-1), self._glm())
@@ -611,6 +615,7 @@ class VAE(nn.Module):
         self.epoch = checkpoint['epoch']
         self.glm_reg_scale = checkpoint['glm_reg_scale']
         self.gp_kl_scale = torch.as_tensor(checkpoint['gp_kl_scale']).to(self.device)
+        self._gp_kl_scale_host = float(torch.as_tensor(checkpoint['gp_kl_scale']).cpu())
         self.inducing_pts = checkpoint['inducing_pts']
 
     # ------------------------------------------------------------------ post-hoc (reconstruction export lives in build_model_recons)
