@@ -23,6 +23,17 @@ LAYERS = [
     ('convt5', ConvSpec('convt', 8, 1, (3, 3, 3), 1), (5, 7, 6)),
 ]
 
+# wide rows (>= 12 positions per row): the geometries that take the row-walking weight-gradient kernel and whole-plane tiles
+WIDE_LAYERS = [
+    ('conv1_wide', ConvSpec('conv', 1, 8, (3, 3, 3), 1), (5, 9, 16)),
+    ('conv2_wide', ConvSpec('conv', 8, 8, (3, 3, 3), 2), (7, 11, 27)),
+    ('conv3_wide', ConvSpec('conv', 8, 16, (3, 3, 3), 1), (4, 7, 15)),
+    ('convt3_wide', ConvSpec('convt', 16, 8, (3, 3, 3), 1), (3, 6, 12)),
+    ('convt4_wide', ConvSpec('convt', 8, 8, (5, 3, 3), 2), (3, 5, 12)),
+    ('convt4hr_wide', ConvSpec('convt', 8, 8, (4, 4, 4), 2), (3, 3, 12)),
+    ('convt5_wide', ConvSpec('convt', 8, 1, (3, 3, 3), 1), (4, 7, 13)),
+]
+
 
 def ref_layer(p, w, b, gamma, beta, spec, relu_in, per_group):
     h = F.relu(p) if relu_in else p

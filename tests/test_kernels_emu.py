@@ -38,6 +38,12 @@ def test_layer_relu_only(name, spec, isz):
     K.run_layer_case('cpu', name, spec, isz, with_bn=False, relu_in=True, groups=1, seed=3)
 
 
+@pytest.mark.parametrize('name,spec,isz', K.WIDE_LAYERS, ids=[l[0] for l in K.WIDE_LAYERS])
+def test_layer_wide_rows(name, spec, isz):
+    K.run_layer_case('cpu', name, spec, isz, with_bn=name.startswith(('conv1', 'conv3', 'convt3', 'convt5')), relu_in=not name.startswith('conv1'),
+                     groups=2 if spec.kind == 'convt' else 1, seed=11)
+
+
 def test_first_layer_input_is_data():
     name, spec, isz = K.LAYERS[0]
     K.run_layer_case('cpu', name, spec, isz, with_bn=True, relu_in=False, groups=1, input_is_data=True, seed=5)

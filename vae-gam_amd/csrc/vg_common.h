@@ -22,6 +22,18 @@ static inline void vg_launch(K kernel, dim3 grid, dim3 block, size_t shmem, hipS
 
 #define VG_WAVE 64
 
+// blocks of `kernel` (block size, dynamic LDS bytes) that fit one CU at once: a persistent grid is sized to exactly the
+// resident blocks (a larger grid runs its surplus blocks as a second, mostly idle round)
+#ifdef VG_EMU
+static inline int vg_blocks_per_cu(const void*, int, size_t shmem) { int n = (int)((160 * 1024) / (shmem ? shmem : 1)); return n < 1 ? 1 : (n > 8 ? 8 : n); }
+#else
+static inline int vg_blocks_per_cu(const void* kernel, int block, size_t shmem) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, shmem) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 1; }
+    return n;
+}
+#endif
+
 // wave index inside the block as a wave-uniform (scalar) value: row/tile decoding that depends only
 // on it then runs on the scalar ALU
 #ifdef VG_EMU

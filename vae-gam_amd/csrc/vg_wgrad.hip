@@ -12,6 +12,7 @@
 //   "wide" variant  : CB*CA*KVOL <= 216 (conv1 / convt5, one side has a single channel): every
 //                     thread owns ALL of dw for its own positions; wave-shuffle + LDS reduction.
 #include "vg_common.h"
+#include <stdlib.h>
 #include "../../include/vaegam.h"
 
 namespace {
@@ -710,6 +711,250 @@ int launch_plane(const vg_wgrad_desc* d, const float* a, const float* b, const f
 }
 
 // ------------------------------------------------------------------------------------------
+// Row-walking MFMA variant (layers whose position rows are >= 12 wide: the four large decoder layers, conv1-3).
+// Same GEMM and operand images as wgrad_plane_k, two changes that matter:
+//  * a WAVE owns whole position rows, so (plane, row) are scalars and a k-step (4 consecutive positions of the row)
+//    addresses both operands as  row base + immediate : ~8 VALU instructions beside TC matrix instructions instead of
+//    the ~35 of the flat-position walk (div/mod-free carry of (dz,py,px) per lane, masks, offset rebuilds);
+//  * the `a` slot holds only the ROWS the tile's windows touch ((TPH-1)*S+KH rows of each plane, still one contiguous
+//    span per plane for the flat LDS-DMA), so a tile is ~20-30 KB instead of 60 KB and 3-8 blocks share a CU: one
+//    block's DMA + barriers hide behind the others' MFMAs.
+// ------------------------------------------------------------------------------------------
+template <int V> struct vg_int { static constexpr int value = V; };
+
+struct WgradRowsParams {
+    vg_wgrad_desc d;
+    int TPD, TPH, nph, pdblocks;
+    int LD, AR, apl;            // a planes / rows per plane in a slot; floats per slot plane (AR*AW)
+    int a_slot, a_front;        // floats per a channel slot (with slack both ends); front slack
+    int nbuf;                   // CA: all channels resident; 2: double-buffered over the channel loop; 1: single
+    int b_off, bch;
+    int lds_floats;
+    int items;
+};
+
+template <int CA, int TC, int KD, int KH, int KW, int S, bool PAD, bool PA>
+__global__ void __launch_bounds__(256)
+wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ in_scale,
+             const float* __restrict__ in_shift, float* __restrict__ ws, WgradRowsParams p) {
+    VG_DYN_SMEM(float, lds);
+    constexpr int KVOL = KD * KH * KW;
+    constexpr int NT = CA * TC;
+    constexpr int UG = 3;
+    const vg_wgrad_desc& d = p.d;
+    const int CB = d.CB;
+    const int tid = threadIdx.x, lane = tid % VG_WAVE;
+    const int wave = vg_wave_id(), nwaves = blockDim.x / VG_WAVE;
+    float* btile = lds + p.b_off;
+    const int kq = lane >> 4, cbl = lane & 15;
+
+    for (int i = tid; i < p.lds_floats; i += blockDim.x) lds[i] = 0.f;       // never-written words stay finite
+
+    int colOff[TC], tkd[TC], tkh[TC], tkw[TC];
+#pragma unroll
+    for (int t = 0; t < TC; ++t) {
+        const int tap = t * 16 + cbl;
+        const bool ok = tap < KVOL;
+        tkd[t] = ok ? tap / (KH * KW) : 0; tkh[t] = ok ? (tap / KW) % KH : 0; tkw[t] = ok ? tap % KW : 0;
+        colOff[t] = tkd[t] * p.apl + tkh[t] * d.AW + tkw[t];
+    }
+    vg_f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { acc[t].v[0] = 0.f; acc[t].v[1] = 0.f; acc[t].v[2] = 0.f; acc[t].v[3] = 0.f; }
+
+    const int rl_a = PA ? d.relu_in : 0, rl_b = PA ? 0 : d.relu_in;           // PA: the ReLU / BN affine belongs to the window tensor
+    const float lo_a = rl_a ? 0.f : -__builtin_inff(), lo_b = rl_b ? 0.f : -__builtin_inff();
+    const int ksteps = (d.PW + 3) / 4;
+    const int aplane = d.AH * d.AW, bplane = d.PH * d.PW;
+    const bool cb_ok = cbl < CB;
+    const float* bchan = btile + min(cbl, CB - 1) * p.bch + kq;
+    __syncthreads();
+
+    for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
+        const int n = item / (p.pdblocks * p.nph); const int rem = item % (p.pdblocks * p.nph);
+        const int pd0 = (rem / p.nph) * p.TPD, ph0 = (rem % p.nph) * p.TPH;
+        const int nrow = min(p.TPH, d.PH - ph0), ndz = min(p.TPD, d.PD - pd0);
+        const int g = (in_scale != nullptr) ? n / d.per_group : 0;
+        const int ap0 = pd0 * S - d.pad_d, ih0 = ph0 * S - d.pad_h;
+        const int pl_lo = max(ap0, 0), pl_hi = min(ap0 + p.LD, d.AD);
+        const int r_lo = max(ih0, 0), r_hi = min(ih0 + p.AR, d.AH);
+        const int npl = max(pl_hi - pl_lo, 0);
+        const int cnt = max(r_hi - r_lo, 0) * d.AW;                         // contiguous floats per staged plane
+        const int chunks = (cnt + VG_WAVE - 1) / VG_WAVE;
+        const int adst = p.a_front + (pl_lo - ap0) * p.apl + (r_lo - ih0) * d.AW;
+        const float* abase = a + (((size_t)n * CA * d.AD + pl_lo) * d.AH + r_lo) * d.AW;
+        float bsc = 1.f, bsh = 0.f;
+        if (!PA && in_scale && cb_ok) { bsc = in_scale[g * CB + cbl]; bsh = in_shift[g * CB + cbl]; }
+        __syncthreads();                                                  // previous item's tiles fully consumed
+        // one (channel, plane) span per wave at a time: the span's base addresses are formed once, the 256-byte DMA
+        // instructions of the span then cost a handful of scalar adds each (a flattened loop pays two scalar divisions
+        // and 64-bit address arithmetic -- ~75 SALU instructions -- per DMA instruction)
+        auto stage_a = [&](int c0, int nc, int slot0) {
+            for (int q = wave; q < nc * npl; q += nwaves) {
+                const int c = q / npl, pl = q - c * npl;
+                const float* src = abase + ((size_t)(c0 + c) * d.AD + pl) * aplane + lane;
+                float* dst = lds + (slot0 + c) * p.a_slot + adst + pl * p.apl;
+                for (int o = 0; o < cnt; o += VG_WAVE)
+                    if (o + lane < cnt) vg_dma4(src + o, dst + o);
+            }
+        };
+        if (p.nbuf == CA) stage_a(0, CA, 0);
+        else stage_a(0, 1, 0);
+        {
+            const int nb = nrow * d.PW;
+            for (int cz = wave; cz < CB * ndz; cz += nwaves) {
+                const int c = cz / ndz, dz = cz - c * ndz;
+                const float* src = b + (((size_t)n * CB + c) * d.PD + pd0 + dz) * bplane + (size_t)ph0 * d.PW + lane;
+                float* dst = btile + c * p.bch + dz * p.TPH * d.PW;
+                for (int o = 0; o < nb; o += VG_WAVE)
+                    if (o + lane < nb) vg_dma4(src + o, dst + o);
+            }
+        }
+        vg_dma_wait();
+        __syncthreads();
+#pragma unroll
+        for (int ca = 0; ca < CA; ++ca) {
+            const float* cur = lds + (ca % p.nbuf) * p.a_slot;
+            if (ca + 1 < CA && p.nbuf == 2) stage_a(ca + 1, 1, (ca + 1) & 1);        // in flight behind this channel's MFMAs
+            float sc = 1.f, sh = 0.f;
+            if (PA && in_scale) { sc = in_scale[g * CA + ca]; sh = in_shift[g * CA + ca]; }
+            for (int r = wave; r < ndz * p.TPH; r += nwaves) {                     // wave-uniform (plane, row)
+                const int dz = r / p.TPH, py = r - dz * p.TPH;
+                if (py >= nrow) continue;
+                const float* bp = bchan + r * d.PW;
+                const float* ap = cur + p.a_front + (dz * S) * p.apl + (py * S) * d.AW + kq * S - d.pad_w;
+                bool okdh[TC];
+                if (PAD) {
+#pragma unroll
+                    for (int t = 0; t < TC; ++t) {
+                        const int id = ap0 + dz * S + tkd[t], ih = ih0 + py * S + tkh[t];
+                        okdh[t] = id >= 0 && id < d.AD && ih >= 0 && ih < d.AH;
+                    }
+                }
+                // NU k-steps per block: all operand reads first, then the matrix instructions -- branch-free, so the LDS
+                // latency is paid once per NU*TC MFMAs (a uniform `continue` inside would put a full s_waitcnt on every read)
+                auto kblock = [&](auto nu_tag, int ks) {
+                    constexpr int NU = decltype(nu_tag)::value;
+                    float av[NU], bv[NU][TC];
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        av[u] = bp[(ks + u) * 4];
+#pragma unroll
+                        for (int t = 0; t < TC; ++t) bv[u][t] = ap[colOff[t] + (ks + u) * 4 * S];
+                    }
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int px = (ks + u) * 4 + kq;
+                        const bool pok = px < d.PW;
+                        const float a_ = (pok && cb_ok) ? (PA ? av[u] : fmaf(fmaxf(av[u], lo_b), bsc, bsh)) : 0.f;
+#pragma unroll
+                        for (int t = 0; t < TC; ++t) {
+                            float b_ = bv[u][t];
+                            if (PA) b_ = fmaf(fmaxf(b_, lo_a), sc, sh);
+                            if (PAD) {
+                                const int iw = px * S - d.pad_w + tkw[t];
+                                b_ = (okdh[t] && iw >= 0 && iw < d.AW) ? b_ : 0.f;
+                            }
+                            vg_mfma16(a_, b_, acc[ca * TC + t]);
+                        }
+                    }
+                };
+                int ks = 0;
+                for (; ks + UG <= ksteps; ks += UG) kblock(vg_int<UG>{}, ks);
+                if (ksteps - ks == 2) kblock(vg_int<2>{}, ks);
+                else if (ksteps - ks == 1) kblock(vg_int<1>{}, ks);
+            }
+            if (CA > 1 && p.nbuf != CA) {
+                if (p.nbuf == 2) { vg_dma_wait(); __syncthreads(); }
+                else if (ca + 1 < CA) { __syncthreads(); stage_a(ca + 1, 1, 0); vg_dma_wait(); __syncthreads(); }
+            }
+        }
+    }
+    // ---- cross-wave reduction through LDS (one wave at a time), then one slab per block
+    float* red = lds;
+    __syncthreads();
+    for (int w = 0; w < nwaves; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int idx = (t * 4 + r) * VG_WAVE + lane;
+                    red[idx] = (w == 0 ? 0.f : red[idx]) + acc[t].v[r];
+                }
+        }
+        __syncthreads();
+    }
+    const int ncol = CA * KVOL;
+    float* out = ws + (size_t)blockIdx.x * CB * ncol;
+    for (int i = tid; i < NT * 4 * VG_WAVE; i += blockDim.x) {
+        const int l = i % VG_WAVE; const int r = (i / VG_WAVE) % 4; const int t = i / (4 * VG_WAVE);
+        const int ca = t / TC, tap = (t % TC) * 16 + (l & 15);
+        const int cb = (l >> 4) * 4 + r;
+        if (cb < CB && tap < KVOL) out[(size_t)cb * ncol + ca * KVOL + tap] = red[i];
+    }
+}
+
+// returns -1 when the geometry does not fit (caller falls back)
+template <int CA, int TC, int KD, int KH, int KW, int S, bool PAD>
+int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const float* in_scale, const float* in_shift,
+                float* ws, float* dw, hipStream_t s, int64_t* ws_bytes_only, int accumulate) {
+    constexpr int KVOL = KD * KH * KW;
+    constexpr int NT = CA * TC;
+    const bool padded = d->pad_d || d->pad_h || d->pad_w;
+    if (padded != PAD || d->CA != CA || d->CB > 16 || d->PW < 12) return -1;
+    if (!PAD && ((d->PD - 1) * S + KD > d->AD || (d->PH - 1) * S + KH > d->AH || (d->PW - 1) * S + KW > d->AW)) return -1;
+    static const long cap_env = getenv("VG_WGRAD_LDS") ? atol(getenv("VG_WGRAD_LDS")) : 0;
+    const size_t cap = cap_env > 0 ? (size_t)cap_env : (size_t)(NT >= 16 ? 40 : 24) * 1024;
+    const size_t red_fl = (size_t)NT * 4 * VG_WAVE;
+    const int front = 64;
+    WgradRowsParams best; double best_score = -1;
+    for (int td = 1; td <= 4 && td <= d->PD; ++td)
+        for (int th = 1; th <= d->PH; ++th) {
+            WgradRowsParams p; p.d = *d;
+            p.TPD = td; p.TPH = th; p.LD = (td - 1) * S + KD; p.AR = (th - 1) * S + KH; p.apl = p.AR * d->AW;
+            p.a_front = front;
+            p.a_slot = (int)((((size_t)p.LD * p.apl + front + 64 + 16 * S + 63) / 64) * 64);
+            size_t f = (size_t)td * th * d->PW + 8; while (f % 32 != 2) ++f;
+            p.bch = (int)f;
+            p.nbuf = 0;
+            const int opts[3] = {CA, 2, 1};
+            for (int k = 0; k < 3 && !p.nbuf; ++k) {
+                const int nb = opts[k];
+                if (nb > CA || (nb == 2 && CA <= 2 && k == 1)) continue;
+                if (((size_t)nb * p.a_slot + (size_t)d->CB * p.bch + 64) * 4 <= cap) p.nbuf = nb;
+            }
+            if (!p.nbuf) continue;
+            const int rows = td * th, pos = rows * d->PW;
+            const double util = ((double)d->PH / (vg_cdiv(d->PH, th) * th)) * ((double)d->PD / (vg_cdiv(d->PD, td) * td)) *
+                                ((double)rows / (4 * vg_cdiv(rows, 4)));
+            const double halo = (double)(td * S) * (th * S) / ((double)p.LD * p.AR);
+            double score = util * pos / (pos + 96.0) * (0.6 + 0.4 * halo);
+            if (p.nbuf == 1 && CA > 1) score *= 0.6;
+            if (score > best_score) { best_score = score; best = p; }
+        }
+    if (best_score < 0) return -1;
+    WgradRowsParams p = best;
+    p.nph = vg_cdiv(d->PH, p.TPH); p.pdblocks = vg_cdiv(d->PD, p.TPD);
+    p.b_off = p.nbuf * p.a_slot;
+    size_t fl = (size_t)p.b_off + (size_t)d->CB * p.bch + 64;
+    if (fl < red_fl) fl = red_fl;
+    p.lds_floats = (int)fl;
+    p.items = d->N * p.pdblocks * p.nph;
+    auto kern = d->pro_on_a ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, true> : wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false>;
+    int per_cu = vg_blocks_per_cu((const void*)kern, 256, fl * sizeof(float));   // persistent grid == resident blocks
+    if (per_cu > 8) per_cu = 8;
+    int grid = 256 * per_cu; if (grid > p.items) grid = p.items;
+    const int len = d->CB * CA * KVOL;
+    if (ws_bytes_only) { *ws_bytes_only = (int64_t)grid * len * sizeof(float); return VG_OK; }
+    vg_launch(kern, dim3(grid), dim3(256), fl * sizeof(float), s, a, b, in_scale, in_shift, ws, p);
+    int rc = vg_check_launch("wgrad_rows");
+    if (rc) return rc;
+    vg_launch(slab_sum_k, dim3(vg_cdiv(len, 64)), dim3(64 * SLAB_ROWS), 0, s, (const float*)ws, grid, len, accumulate, dw);
+    return vg_check_launch("wgrad slab_sum");
+}
+
+// ------------------------------------------------------------------------------------------
 // wide variant: CB = 8, CA = 1, 3x3x3, stride 1, pad 0  (conv1 and convt5)
 // ------------------------------------------------------------------------------------------
 struct WideParams { vg_wgrad_desc d; int wgroups; long long items; };
@@ -815,7 +1060,8 @@ int dispatch(const vg_wgrad_desc* d, const float* a, const float* b, const float
     const bool k333 = d->KD == 3 && d->KH == 3 && d->KW == 3;
     const bool small_w = d->PW <= 8;
 #define PLANE(CA, TC, KD, KH, KW, S) \
-    { int r_ = launch_plane<CA, TC, KD, KH, KW, S, false>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; }
+    { if (!getenv("VG_NO_WGRAD_ROWS")) { int r_ = launch_rows<CA, TC, KD, KH, KW, S, false>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; } \
+      int r_ = launch_plane<CA, TC, KD, KH, KW, S, false>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; }
     if (d->CB <= 16 && d->PW <= 64) {
         if (k333 && d->CA == 1 && d->stride == 1) PLANE(1, 2, 3, 3, 3, 1);
         if (k333 && d->CA == 16 && d->stride == 2 && (d->pad_d || d->pad_h || d->pad_w))
