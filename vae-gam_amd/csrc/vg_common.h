@@ -75,6 +75,27 @@ __device__ __forceinline__ void vg_dma4(const float* gsrc, float* lds_row_base) 
 __device__ __forceinline__ void vg_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
 
+// Wave-cooperative copy of n contiguous floats -> LDS: the full 64-float DMA instructions carry no per-lane predicate
+// (only the tail does), so each costs a scalar add or two.  src_lane = source + lane.
+#ifdef VG_EMU
+static inline void vg_dma_span(const float* src_lane, float* dst, int n, int lane) {
+    for (int o = 0; o + lane < n; o += 64) dst[o + lane] = src_lane[o];
+}
+#else
+__device__ __forceinline__ void vg_dma_span(const float* src_lane, float* dst, int n, int lane) {
+    for (; n >= 64; n -= 64, src_lane += 64, dst += 64) vg_dma4(src_lane, dst);     // running pointers: the tail reuses them
+    if (lane < n) vg_dma4(src_lane, dst);
+}
+#endif
+
+// max(x, lo) as ONE v_max_f32: fmaxf() makes the compiler quiet both inputs first (two extra v_max per call); the operands
+// here are finite activations and lo is 0 or -inf, so IEEE NaN handling is irrelevant.
+#ifdef VG_EMU
+static inline float vg_max(float x, float lo) { return x > lo ? x : lo; }
+#else
+__device__ __forceinline__ float vg_max(float x, float lo) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(lo)); return r; }
+#endif
+
 // fp32-input MFMA, exact fp32 (v_mfma_f32_16x16x4_f32): D(16x16) = A(16x4) * B(4x16) + C.
 // lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; it owns D[row = (l>>4)*4 + r][col = l&15], r = 0..3.
 struct vg_f32x4 { float v[4]; };

@@ -733,14 +733,13 @@ struct WgradRowsParams {
     int items;
 };
 
-template <int CA, int TC, int KD, int KH, int KW, int S, bool PAD, bool PA>
+template <int CA, int TC, int KD, int KH, int KW, int S, bool PAD, bool PA, int UG>
 __global__ void __launch_bounds__(256)
 wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ in_scale,
              const float* __restrict__ in_shift, float* __restrict__ ws, WgradRowsParams p) {
     VG_DYN_SMEM(float, lds);
     constexpr int KVOL = KD * KH * KW;
     constexpr int NT = CA * TC;
-    constexpr int UG = 3;
     const vg_wgrad_desc& d = p.d;
     const int CB = d.CB;
     const int tid = threadIdx.x, lane = tid % VG_WAVE;
@@ -780,34 +779,31 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
         const int r_lo = max(ih0, 0), r_hi = min(ih0 + p.AR, d.AH);
         const int npl = max(pl_hi - pl_lo, 0);
         const int cnt = max(r_hi - r_lo, 0) * d.AW;                         // contiguous floats per staged plane
-        const int chunks = (cnt + VG_WAVE - 1) / VG_WAVE;
         const int adst = p.a_front + (pl_lo - ap0) * p.apl + (r_lo - ih0) * d.AW;
         const float* abase = a + (((size_t)n * CA * d.AD + pl_lo) * d.AH + r_lo) * d.AW;
-        float bsc = 1.f, bsh = 0.f;
+        float bsc = cb_ok ? 1.f : 0.f, bsh = 0.f;                        // lanes without a b channel contribute zeros
         if (!PA && in_scale && cb_ok) { bsc = in_scale[g * CB + cbl]; bsh = in_shift[g * CB + cbl]; }
         __syncthreads();                                                  // previous item's tiles fully consumed
         // one (channel, plane) span per wave at a time: the span's base addresses are formed once, the 256-byte DMA
         // instructions of the span then cost a handful of scalar adds each (a flattened loop pays two scalar divisions
         // and 64-bit address arithmetic -- ~75 SALU instructions -- per DMA instruction)
         auto stage_a = [&](int c0, int nc, int slot0) {
-            for (int q = wave; q < nc * npl; q += nwaves) {
-                const int c = q / npl, pl = q - c * npl;
-                const float* src = abase + ((size_t)(c0 + c) * d.AD + pl) * aplane + lane;
-                float* dst = lds + (slot0 + c) * p.a_slot + adst + pl * p.apl;
-                for (int o = 0; o < cnt; o += VG_WAVE)
-                    if (o + lane < cnt) vg_dma4(src + o, dst + o);
+            for (int c = 0; c < nc; ++c) {
+                const float* src = abase + ((size_t)(c0 + c) * d.AD + wave) * aplane + lane;
+                float* dst = lds + (slot0 + c) * p.a_slot + adst + wave * p.apl;
+                for (int pl = wave; pl < npl; pl += 4, src += 4 * (size_t)aplane, dst += 4 * p.apl) vg_dma_span(src, dst, cnt, lane);
             }
         };
         if (p.nbuf == CA) stage_a(0, CA, 0);
         else stage_a(0, 1, 0);
         {
             const int nb = nrow * d.PW;
-            for (int cz = wave; cz < CB * ndz; cz += nwaves) {
-                const int c = cz / ndz, dz = cz - c * ndz;
-                const float* src = b + (((size_t)n * CB + c) * d.PD + pd0 + dz) * bplane + (size_t)ph0 * d.PW + lane;
-                float* dst = btile + c * p.bch + dz * p.TPH * d.PW;
-                for (int o = 0; o < nb; o += VG_WAVE)
-                    if (o + lane < nb) vg_dma4(src + o, dst + o);
+            const size_t bch_g = (size_t)d.PD * bplane;
+            const float* src_c = b + ((size_t)n * CB + wave) * bch_g + (size_t)pd0 * bplane + (size_t)ph0 * d.PW + lane;
+            float* dst_c = btile + wave * p.bch;
+            for (int c = wave; c < CB; c += 4, src_c += 4 * bch_g, dst_c += 4 * p.bch) {
+                const float* src = src_c; float* dst = dst_c;
+                for (int dz = 0; dz < ndz; ++dz, src += bplane, dst += p.TPH * d.PW) vg_dma_span(src, dst, nb, lane);
             }
         }
         vg_dma_wait();
@@ -818,10 +814,10 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
             if (ca + 1 < CA && p.nbuf == 2) stage_a(ca + 1, 1, (ca + 1) & 1);        // in flight behind this channel's MFMAs
             float sc = 1.f, sh = 0.f;
             if (PA && in_scale) { sc = in_scale[g * CA + ca]; sh = in_shift[g * CA + ca]; }
-            for (int r = wave; r < ndz * p.TPH; r += nwaves) {                     // wave-uniform (plane, row)
-                const int dz = r / p.TPH, py = r - dz * p.TPH;
-                if (py >= nrow) continue;
-                const float* bp = bchan + r * d.PW;
+            // rows of the tile dealt round-robin over the 4 waves ((plane, row) wave-uniform: scalars, no division)
+            for (int dz = 0; dz < ndz; ++dz)
+            for (int py = (wave - dz * nrow) & 3; py < nrow; py += 4) {
+                const float* bp = bchan + (dz * p.TPH + py) * d.PW;
                 const float* ap = cur + p.a_front + (dz * S) * p.apl + (py * S) * d.AW + kq * S - d.pad_w;
                 bool okdh[TC];
                 if (PAD) {
@@ -831,26 +827,28 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
                         okdh[t] = id >= 0 && id < d.AD && ih >= 0 && ih < d.AH;
                     }
                 }
-                // NU k-steps per block: all operand reads first, then the matrix instructions -- branch-free, so the LDS
-                // latency is paid once per NU*TC MFMAs (a uniform `continue` inside would put a full s_waitcnt on every read)
-                auto kblock = [&](auto nu_tag, int ks) {
-                    constexpr int NU = decltype(nu_tag)::value;
-                    float av[NU], bv[NU][TC];
+                // UG k-steps per iteration: all operand reads first, then the matrix instructions.  ONE branch-free loop:
+                // the trip count is rounded up to UG (the surplus k-steps have px >= PW, their A operand is zeroed and
+                // their reads stay inside the tiles' slack) -- a remainder branch would split the accumulators' live
+                // ranges and the compiler then shuffles all NT*4 of them between register sets on every row.
+                auto kblock = [&](auto masked_tag, int ks) {
+                    constexpr bool MASKED = decltype(masked_tag)::value != 0;
+                    float av[UG], bv[UG][TC];
 #pragma unroll
-                    for (int u = 0; u < NU; ++u) {
+                    for (int u = 0; u < UG; ++u) {
                         av[u] = bp[(ks + u) * 4];
 #pragma unroll
                         for (int t = 0; t < TC; ++t) bv[u][t] = ap[colOff[t] + (ks + u) * 4 * S];
                     }
 #pragma unroll
-                    for (int u = 0; u < NU; ++u) {
+                    for (int u = 0; u < UG; ++u) {
                         const int px = (ks + u) * 4 + kq;
-                        const bool pok = px < d.PW;
-                        const float a_ = (pok && cb_ok) ? (PA ? av[u] : fmaf(fmaxf(av[u], lo_b), bsc, bsh)) : 0.f;
+                        float a_ = fmaf(vg_max(av[u], lo_b), bsc, bsh);           // PA: lo_b = -inf, bsc = 1 (0 for idle lanes), bsh = 0
+                        if (MASKED) a_ = px < d.PW ? a_ : 0.f;
 #pragma unroll
                         for (int t = 0; t < TC; ++t) {
                             float b_ = bv[u][t];
-                            if (PA) b_ = fmaf(fmaxf(b_, lo_a), sc, sh);
+                            if (PA) b_ = fmaf(vg_max(b_, lo_a), sc, sh);
                             if (PAD) {
                                 const int iw = px * S - d.pad_w + tkw[t];
                                 b_ = (okdh[t] && iw >= 0 && iw < d.AW) ? b_ : 0.f;
@@ -859,10 +857,10 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
                         }
                     }
                 };
+                // only the LAST block of k-steps can hold positions past the row's end: it alone carries the mask
                 int ks = 0;
-                for (; ks + UG <= ksteps; ks += UG) kblock(vg_int<UG>{}, ks);
-                if (ksteps - ks == 2) kblock(vg_int<2>{}, ks);
-                else if (ksteps - ks == 1) kblock(vg_int<1>{}, ks);
+                for (; ks < ksteps - UG; ks += UG) kblock(vg_int<0>{}, ks);
+                kblock(vg_int<1>{}, ks);
             }
             if (CA > 1 && p.nbuf != CA) {
                 if (p.nbuf == 2) { vg_dma_wait(); __syncthreads(); }
@@ -914,8 +912,8 @@ int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const fl
             WgradRowsParams p; p.d = *d;
             p.TPD = td; p.TPH = th; p.LD = (td - 1) * S + KD; p.AR = (th - 1) * S + KH; p.apl = p.AR * d->AW;
             p.a_front = front;
-            p.a_slot = (int)((((size_t)p.LD * p.apl + front + 64 + 16 * S + 63) / 64) * 64);
-            size_t f = (size_t)td * th * d->PW + 8; while (f % 32 != 2) ++f;
+            p.a_slot = (int)((((size_t)p.LD * p.apl + front + 64 + 32 * S + 63) / 64) * 64);
+            size_t f = (size_t)td * th * d->PW + 24; while (f % 32 != 2) ++f;       // +24: rounded-up k-steps read past the last row
             p.bch = (int)f;
             p.nbuf = 0;
             const int opts[3] = {CA, 2, 1};
@@ -941,7 +939,14 @@ int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const fl
     if (fl < red_fl) fl = red_fl;
     p.lds_floats = (int)fl;
     p.items = d->N * p.pdblocks * p.nph;
-    auto kern = d->pro_on_a ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, true> : wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false>;
+    // k-steps (4 positions) per row, rounded up to the unroll that wastes the fewest
+    const int ksteps = vg_cdiv(d->PW, 4);
+    int ug = 4, waste = vg_cdiv(ksteps, 4) * 4 - ksteps;
+    for (int u = 3; u >= 2; --u) { const int w_ = vg_cdiv(ksteps, u) * u - ksteps; if (w_ < waste) { waste = w_; ug = u; } }
+    using kern_t = void (*)(const float*, const float*, const float*, const float*, float*, WgradRowsParams);
+    kern_t kern;
+    if (d->pro_on_a) kern = ug == 4 ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, true, 4> : ug == 3 ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, true, 3> : wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, true, 2>;
+    else kern = ug == 4 ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 4> : ug == 3 ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 3> : wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 2>;
     int per_cu = vg_blocks_per_cu((const void*)kern, 256, fl * sizeof(float));   // persistent grid == resident blocks
     if (per_cu > 8) per_cu = 8;
     int grid = 256 * per_cu; if (grid > p.items) grid = p.items;
