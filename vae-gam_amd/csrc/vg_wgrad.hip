@@ -721,6 +721,8 @@ int launch_plane(const vg_wgrad_desc* d, const float* a, const float* b, const f
 //    block's DMA + barriers hide behind the others' MFMAs.
 // ------------------------------------------------------------------------------------------
 template <int V> struct vg_int { static constexpr int value = V; };
+template <int N, int I = 0, typename F>
+__host__ __device__ inline void vg_static_for(F&& f) { if constexpr (I < N) { f(vg_int<I>{}); vg_static_for<N, I + 1>(f); } }
 
 struct WgradRowsParams {
     vg_wgrad_desc d;
@@ -733,7 +735,7 @@ struct WgradRowsParams {
     int items;
 };
 
-template <int CA, int TC, int KD, int KH, int KW, int S, bool PAD, bool PA, int UG>
+template <int CA, int TC, int KD, int KH, int KW, int S, bool PAD, bool PA, int UG, bool RES>
 __global__ void __launch_bounds__(256)
 wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ in_scale,
              const float* __restrict__ in_shift, float* __restrict__ ws, WgradRowsParams p) {
@@ -794,7 +796,7 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
                 for (int pl = wave; pl < npl; pl += 4, src += 4 * (size_t)aplane, dst += 4 * p.apl) vg_dma_span(src, dst, cnt, lane);
             }
         };
-        if (p.nbuf == CA) stage_a(0, CA, 0);
+        if (RES) stage_a(0, CA, 0);
         else stage_a(0, 1, 0);
         {
             const int nb = nrow * d.PW;
@@ -808,64 +810,91 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
         }
         vg_dma_wait();
         __syncthreads();
+        // one position row against one `a` channel: UG k-steps per iteration, all operand reads first, then the matrix
+        // instructions.  ONE branch-free loop whose trip count is rounded up to UG (surplus k-steps have px >= PW: their A
+        // operand is zeroed, their reads stay inside the tiles' slack); only the LAST block can hold such positions and it
+        // alone carries the mask.  (A remainder branch would split the accumulators' live ranges: the compiler then
+        // shuffles all NT*4 of them between register sets on every row.)
+        auto row_channel = [&](auto ca_tag, const float* bp, const float* ap, float sc, float sh, const bool* okdh) {
+            constexpr int ca = decltype(ca_tag)::value;
+            auto kblock = [&](auto masked_tag, int ks) {
+                constexpr bool MASKED = decltype(masked_tag)::value != 0;
+                float av[UG], bv[UG][TC];
 #pragma unroll
-        for (int ca = 0; ca < CA; ++ca) {
-            const float* cur = lds + (ca % p.nbuf) * p.a_slot;
-            if (ca + 1 < CA && p.nbuf == 2) stage_a(ca + 1, 1, (ca + 1) & 1);        // in flight behind this channel's MFMAs
-            float sc = 1.f, sh = 0.f;
-            if (PA && in_scale) { sc = in_scale[g * CA + ca]; sh = in_shift[g * CA + ca]; }
-            // rows of the tile dealt round-robin over the 4 waves ((plane, row) wave-uniform: scalars, no division)
+                for (int u = 0; u < UG; ++u) {
+                    av[u] = bp[(ks + u) * 4];
+#pragma unroll
+                    for (int t = 0; t < TC; ++t) bv[u][t] = ap[colOff[t] + (ks + u) * 4 * S];
+                }
+#pragma unroll
+                for (int u = 0; u < UG; ++u) {
+                    const int px = (ks + u) * 4 + kq;
+                    float a_ = fmaf(vg_max(av[u], lo_b), bsc, bsh);               // PA: lo_b = -inf, bsc = 1 (0 for idle lanes), bsh = 0
+                    if (MASKED) a_ = px < d.PW ? a_ : 0.f;
+#pragma unroll
+                    for (int t = 0; t < TC; ++t) {
+                        float b_ = bv[u][t];
+                        if (PA) b_ = fmaf(vg_max(b_, lo_a), sc, sh);
+                        if (PAD) {
+                            const int iw = px * S - d.pad_w + tkw[t];
+                            b_ = (okdh[t] && iw >= 0 && iw < d.AW) ? b_ : 0.f;
+                        }
+                        vg_mfma16(a_, b_, acc[ca * TC + t]);
+                    }
+                }
+            };
+            int ks = 0;
+            for (; ks < ksteps - UG; ks += UG) kblock(vg_int<0>{}, ks);
+            kblock(vg_int<1>{}, ks);
+        };
+        auto row_masks = [&](int dz, int py, bool* okdh) {
+#pragma unroll
+            for (int t = 0; t < TC; ++t) {
+                const int id = ap0 + dz * S + tkd[t], ih = ih0 + py * S + tkh[t];
+                okdh[t] = !PAD || (id >= 0 && id < d.AD && ih >= 0 && ih < d.AH);
+            }
+        };
+        if constexpr (RES) {
+            // every channel's window rows are resident: rows outermost, so the row bookkeeping (and the masks) are paid
+            // once per row, not once per (row, channel) -- the small layers (5..7 positions per row) live on this
+            float scv[CA], shv[CA];
+#pragma unroll
+            for (int ca = 0; ca < CA; ++ca) {
+                scv[ca] = 1.f; shv[ca] = 0.f;
+                if (PA && in_scale) { scv[ca] = in_scale[g * CA + ca]; shv[ca] = in_shift[g * CA + ca]; }
+            }
             for (int dz = 0; dz < ndz; ++dz)
             for (int py = (wave - dz * nrow) & 3; py < nrow; py += 4) {
                 const float* bp = bchan + (dz * p.TPH + py) * d.PW;
-                const float* ap = cur + p.a_front + (dz * S) * p.apl + (py * S) * d.AW + kq * S - d.pad_w;
+                const float* ap0_ = lds + p.a_front + (dz * S) * p.apl + (py * S) * d.AW + kq * S - d.pad_w;
                 bool okdh[TC];
-                if (PAD) {
-#pragma unroll
-                    for (int t = 0; t < TC; ++t) {
-                        const int id = ap0 + dz * S + tkd[t], ih = ih0 + py * S + tkh[t];
-                        okdh[t] = id >= 0 && id < d.AD && ih >= 0 && ih < d.AH;
-                    }
+                row_masks(dz, py, okdh);
+                vg_static_for<CA>([&](auto ca_tag) {
+                    constexpr int ca = decltype(ca_tag)::value;
+                    row_channel(ca_tag, bp, ap0_ + ca * p.a_slot, scv[ca], shv[ca], okdh);
+                });
+            }
+        } else {
+            vg_static_for<CA>([&](auto ca_tag) {
+                constexpr int ca = decltype(ca_tag)::value;
+                const float* cur = lds + (ca % p.nbuf) * p.a_slot;
+                if (ca + 1 < CA && p.nbuf == 2) stage_a(ca + 1, 1, (ca + 1) & 1);    // in flight behind this channel's MFMAs
+                float sc = 1.f, sh = 0.f;
+                if (PA && in_scale) { sc = in_scale[g * CA + ca]; sh = in_shift[g * CA + ca]; }
+                // rows of the tile dealt round-robin over the 4 waves ((plane, row) wave-uniform: scalars, no division)
+                for (int dz = 0; dz < ndz; ++dz)
+                for (int py = (wave - dz * nrow) & 3; py < nrow; py += 4) {
+                    const float* bp = bchan + (dz * p.TPH + py) * d.PW;
+                    const float* ap = cur + p.a_front + (dz * S) * p.apl + (py * S) * d.AW + kq * S - d.pad_w;
+                    bool okdh[TC];
+                    row_masks(dz, py, okdh);
+                    row_channel(ca_tag, bp, ap, sc, sh, okdh);
                 }
-                // UG k-steps per iteration: all operand reads first, then the matrix instructions.  ONE branch-free loop:
-                // the trip count is rounded up to UG (the surplus k-steps have px >= PW, their A operand is zeroed and
-                // their reads stay inside the tiles' slack) -- a remainder branch would split the accumulators' live
-                // ranges and the compiler then shuffles all NT*4 of them between register sets on every row.
-                auto kblock = [&](auto masked_tag, int ks) {
-                    constexpr bool MASKED = decltype(masked_tag)::value != 0;
-                    float av[UG], bv[UG][TC];
-#pragma unroll
-                    for (int u = 0; u < UG; ++u) {
-                        av[u] = bp[(ks + u) * 4];
-#pragma unroll
-                        for (int t = 0; t < TC; ++t) bv[u][t] = ap[colOff[t] + (ks + u) * 4 * S];
-                    }
-#pragma unroll
-                    for (int u = 0; u < UG; ++u) {
-                        const int px = (ks + u) * 4 + kq;
-                        float a_ = fmaf(vg_max(av[u], lo_b), bsc, bsh);           // PA: lo_b = -inf, bsc = 1 (0 for idle lanes), bsh = 0
-                        if (MASKED) a_ = px < d.PW ? a_ : 0.f;
-#pragma unroll
-                        for (int t = 0; t < TC; ++t) {
-                            float b_ = bv[u][t];
-                            if (PA) b_ = fmaf(vg_max(b_, lo_a), sc, sh);
-                            if (PAD) {
-                                const int iw = px * S - d.pad_w + tkw[t];
-                                b_ = (okdh[t] && iw >= 0 && iw < d.AW) ? b_ : 0.f;
-                            }
-                            vg_mfma16(a_, b_, acc[ca * TC + t]);
-                        }
-                    }
-                };
-                // only the LAST block of k-steps can hold positions past the row's end: it alone carries the mask
-                int ks = 0;
-                for (; ks < ksteps - UG; ks += UG) kblock(vg_int<0>{}, ks);
-                kblock(vg_int<1>{}, ks);
-            }
-            if (CA > 1 && p.nbuf != CA) {
-                if (p.nbuf == 2) { vg_dma_wait(); __syncthreads(); }
-                else if (ca + 1 < CA) { __syncthreads(); stage_a(ca + 1, 1, 0); vg_dma_wait(); __syncthreads(); }
-            }
+                if (CA > 1) {
+                    if (p.nbuf == 2) { vg_dma_wait(); __syncthreads(); }
+                    else if (ca + 1 < CA) { __syncthreads(); stage_a(ca + 1, 1, 0); vg_dma_wait(); __syncthreads(); }
+                }
+            });
         }
     }
     // ---- cross-wave reduction through LDS (one wave at a time), then one slab per block
@@ -900,19 +929,20 @@ int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const fl
     constexpr int KVOL = KD * KH * KW;
     constexpr int NT = CA * TC;
     const bool padded = d->pad_d || d->pad_h || d->pad_w;
-    if (padded != PAD || d->CA != CA || d->CB > 16 || d->PW < 12) return -1;
+    if (padded != PAD || d->CA != CA || d->CB > 16) return -1;
+    const bool narrow = d->PW < 12;                 // 5..7-position rows: only worth it with every channel resident (rows outermost)
     if (!PAD && ((d->PD - 1) * S + KD > d->AD || (d->PH - 1) * S + KH > d->AH || (d->PW - 1) * S + KW > d->AW)) return -1;
     static const long cap_env = getenv("VG_WGRAD_LDS") ? atol(getenv("VG_WGRAD_LDS")) : 0;
-    const size_t cap = cap_env > 0 ? (size_t)cap_env : (size_t)(NT >= 16 ? 40 : 24) * 1024;
+    const size_t cap = cap_env > 0 ? (size_t)cap_env : (size_t)(narrow ? 48 : NT >= 16 ? 40 : 24) * 1024;
     const size_t red_fl = (size_t)NT * 4 * VG_WAVE;
-    const int front = 64;
+    const int front = 4;                            // >= pad_w: the first window of a padded row starts before the slot's row
     WgradRowsParams best; double best_score = -1;
     for (int td = 1; td <= 4 && td <= d->PD; ++td)
         for (int th = 1; th <= d->PH; ++th) {
             WgradRowsParams p; p.d = *d;
             p.TPD = td; p.TPH = th; p.LD = (td - 1) * S + KD; p.AR = (th - 1) * S + KH; p.apl = p.AR * d->AW;
             p.a_front = front;
-            p.a_slot = (int)((((size_t)p.LD * p.apl + front + 64 + 32 * S + 63) / 64) * 64);
+            p.a_slot = (int)((((size_t)p.LD * p.apl + front + 4 + 16 * S + 3) / 4) * 4);     // back slack: rounded-up k-steps of the last row
             size_t f = (size_t)td * th * d->PW + 24; while (f % 32 != 2) ++f;       // +24: rounded-up k-steps read past the last row
             p.bch = (int)f;
             p.nbuf = 0;
@@ -922,7 +952,7 @@ int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const fl
                 if (nb > CA || (nb == 2 && CA <= 2 && k == 1)) continue;
                 if (((size_t)nb * p.a_slot + (size_t)d->CB * p.bch + 64) * 4 <= cap) p.nbuf = nb;
             }
-            if (!p.nbuf) continue;
+            if (!p.nbuf || (narrow && p.nbuf != CA)) continue;
             const int rows = td * th, pos = rows * d->PW;
             const double util = ((double)d->PH / (vg_cdiv(d->PH, th) * th)) * ((double)d->PD / (vg_cdiv(d->PD, td) * td)) *
                                 ((double)rows / (4 * vg_cdiv(rows, 4)));
@@ -945,8 +975,11 @@ int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const fl
     for (int u = 3; u >= 2; --u) { const int w_ = vg_cdiv(ksteps, u) * u - ksteps; if (w_ < waste) { waste = w_; ug = u; } }
     using kern_t = void (*)(const float*, const float*, const float*, const float*, float*, WgradRowsParams);
     kern_t kern;
-    if (d->pro_on_a) kern = ug == 4 ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, true, 4> : ug == 3 ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, true, 3> : wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, true, 2>;
-    else kern = ug == 4 ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 4> : ug == 3 ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 3> : wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 2>;
+    const bool res = CA > 1 && p.nbuf == CA;
+#define VG_PICK(PA_, RES_) (ug == 4 ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, PA_, 4, RES_> : ug == 3 ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, PA_, 3, RES_> : wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, PA_, 2, RES_>)
+    if (CA > 1 && res) kern = d->pro_on_a ? VG_PICK(true, true) : VG_PICK(false, true);
+    else kern = d->pro_on_a ? VG_PICK(true, false) : VG_PICK(false, false);
+#undef VG_PICK
     int per_cu = vg_blocks_per_cu((const void*)kern, 256, fl * sizeof(float));   // persistent grid == resident blocks
     if (per_cu > 8) per_cu = 8;
     int grid = 256 * per_cu; if (grid > p.items) grid = p.items;
@@ -1070,7 +1103,8 @@ int dispatch(const vg_wgrad_desc* d, const float* a, const float* b, const float
     if (d->CB <= 16 && d->PW <= 64) {
         if (k333 && d->CA == 1 && d->stride == 1) PLANE(1, 2, 3, 3, 3, 1);
         if (k333 && d->CA == 16 && d->stride == 2 && (d->pad_d || d->pad_h || d->pad_w))
-            { int r_ = launch_plane<16, 2, 3, 3, 3, 2, true>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; }
+            { if (!getenv("VG_NO_WGRAD_ROWS")) { int r_ = launch_rows<16, 2, 3, 3, 3, 2, true>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; }
+              int r_ = launch_plane<16, 2, 3, 3, 3, 2, true>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; }
         if (k333 && d->CA == 8 && d->stride == 1) PLANE(8, 2, 3, 3, 3, 1);
         if (k333 && d->CA == 8 && d->stride == 2) PLANE(8, 2, 3, 3, 3, 2);
         if (k333 && d->CA == 16 && d->stride == 1) PLANE(16, 2, 3, 3, 3, 1);
