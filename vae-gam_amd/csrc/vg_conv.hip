@@ -119,7 +119,7 @@ corr3d_direct_k(const float* __restrict__ x, const float* __restrict__ wpk, cons
                 float seg[RW];
 #pragma unroll
                 for (int i = 0; i < RW; ++i) {
-                    const float v = fmaf(fmaxf(buf[dz & 1][hy][i], lo), sc, sh);
+                    const float v = fmaf(vg_max(buf[dz & 1][hy][i], lo), sc, sh);
                     seg[i] = (rok[dz][hy] && cok[i]) ? v : 0.f;               // zero padding outside the input
                 }
 #pragma unroll
@@ -247,7 +247,7 @@ struct CorrPlaneParams {
 constexpr int PLANE_SLACK = 8;  // floats in front of the LDS buffer: a window may start at iw = -pad
 
 template <int COT, int KD, int KH, int KW, int S, int TDt, int THt, int TW>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
 corr3d_plane_k(const float* __restrict__ x, const float* __restrict__ wpk, const float* __restrict__ bias,
                const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                const float* __restrict__ mask_src, float* __restrict__ y, CorrPlaneParams p) {
@@ -330,7 +330,7 @@ corr3d_plane_k(const float* __restrict__ x, const float* __restrict__ wpk, const
                         float seg[RW];
 #pragma unroll
                         for (int i = 0; i < RW; ++i) {
-                            const float v = fmaf(fmaxf(row[i], lo), sc, sh);
+                            const float v = fmaf(vg_max(row[i], lo), sc, sh);
                             seg[i] = (rok[dz][hy] && cok[i]) ? v : 0.f;
                         }
 #pragma unroll
@@ -562,7 +562,7 @@ corr3d_mfma_k(const float* __restrict__ x, const float* __restrict__ wpk, const 
                 for (int g = 0; g < NG; ++g) {
                     if ((g * nwaves + wave) * 16 >= npos) continue;
                     const bool ok = (vm[g] >> ks) & 1u;
-                    const float b_ = ok ? fmaf(fmaxf(bv[g], lo), sc, sh) : 0.f;
+                    const float b_ = ok ? fmaf(vg_max(bv[g], lo), sc, sh) : 0.f;
                     vg_mfma16(aw, b_, acc[g]);
                 }
             }
@@ -695,7 +695,7 @@ tconv3d_s2_k(const float* __restrict__ x, const float* __restrict__ wpk, const f
             for (int mh = 0; mh < MH; ++mh)
 #pragma unroll
                 for (int mw = 0; mw < MW; ++mw) {
-                    const float v = fmaf(fmaxf(nxt[md][mh][mw], lo), sc, sh);
+                    const float v = fmaf(vg_max(nxt[md][mh][mw], lo), sc, sh);
                     xin[md][mh][mw] = (rok[md][mh] && cok[mw]) ? v : 0.f;
                     nxt[md][mh][mw] = xn[roff[md][mh] + cof[mw]];
                 }
