@@ -88,6 +88,17 @@ __device__ __forceinline__ void vg_dma_span(const float* src_lane, float* dst, i
 }
 #endif
 
+// Read-only kernel arguments that must stay on the SCALAR load path (weights indexed by wave-uniform values): loads through
+// the constant address space are invariant by definition, so the compiler keeps them s_load even in kernels that also
+// store to LDS/global (where its no-clobber analysis otherwise gives up and turns them into per-lane VMEM loads + VGPRs).
+#ifdef VG_EMU
+typedef const float* vg_cptr;
+#define VG_CPTR(p) (p)
+#else
+typedef const __attribute__((address_space(4))) float* vg_cptr;
+#define VG_CPTR(p) ((vg_cptr)(p))
+#endif
+
 // max(x, lo) as ONE v_max_f32: fmaxf() makes the compiler quiet both inputs first (two extra v_max per call); the operands
 // here are finite activations and lo is 0 or -inf, so IEEE NaN handling is irrelevant.
 #ifdef VG_EMU
