@@ -90,12 +90,16 @@ int vg_bn_finalize(const double* sums, int32_t G, int32_t C, const float* gamma,
 /* batch-norm backward through h = relu?(p), xe = (h-mean)*rstd*gamma+beta, given dxe (in place):
  *   dgamma_part[g][c] = sum dxe*hhat, dbeta_part[g][c] = sum dxe,
  *   dp = relu'(p) * gamma*rstd * (dxe - mean(dxe) - hhat*mean(dxe*hhat)).
- * Two entry points so a data-parallel caller can all-reduce the (double[G][C][2]) sums between. */
+ * Two entry points so a data-parallel caller can all-reduce the (double[G][C][2]) sums between.
+ * vg_bn_bwd_apply optionally also returns chsum[c] (+)= sum over samples and positions of dp -- the bias gradient of the
+ * layer that produced p (nn.Conv3d / ConvTranspose3d bias, vae_reg_GP.py:189-215) -- from the values it already holds
+ * (ws: a vg_bn_ws_bytes workspace; chsum NULL = not wanted). */
 int vg_bn_bwd_reduce(const float* dxe, const float* p, int32_t N, int32_t C, int64_t P, int32_t per_group,
                      int32_t relu, const float* mean, const float* rstd, void* ws, double* sums, void* stream);
 int vg_bn_bwd_apply(float* dxe_inout, const float* p, int32_t N, int32_t C, int64_t P, int32_t per_group,
                     int32_t relu, const float* gamma, const float* mean, const float* rstd,
-                    const double* sums, double count, float* dgamma_part, float* dbeta_part, void* stream);
+                    const double* sums, double count, float* dgamma_part, float* dbeta_part,
+                    void* ws, float* chsum, int32_t chsum_accumulate, void* stream);
 
 /* per-channel sum of a [N][C][P] tensor (bias gradients): out[c] = sum_{n,p} x[n][c][p] */
 int vg_channel_sum(const float* x, int32_t N, int32_t C, int64_t P, void* ws, float* out, int32_t accumulate, void* stream);

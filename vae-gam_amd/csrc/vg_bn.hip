@@ -106,7 +106,8 @@ __global__ void bn_finalize_k(const double* __restrict__ sums, int G, int C, con
 __global__ void __launch_bounds__(BN_THREADS)
 bn_bwd_apply_k(float* __restrict__ dxe, const float* __restrict__ p, int C, long long P, int per_group, int relu,
                const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
-               const double* __restrict__ sums, double count, int cp, float* __restrict__ dgamma_part, float* __restrict__ dbeta_part) {
+               const double* __restrict__ sums, double count, int cp, float* __restrict__ dgamma_part, float* __restrict__ dbeta_part,
+               double* __restrict__ csum_part) {
     const int chunk = blockIdx.x, c = blockIdx.y, g = blockIdx.z, chunks = gridDim.x;
     const int cpi = chunk % cp, si = chunk / cp, ns = chunks / cp;
     const int gc = g * C + c;
@@ -117,6 +118,7 @@ bn_bwd_apply_k(float* __restrict__ dxe, const float* __restrict__ p, int C, long
         dbeta_part[gc] = (float)sums[(size_t)gc * 2];
         dgamma_part[gc] = (float)sums[(size_t)gc * 2 + 1];
     }
+    float vs = 0.f;
     for (int nn = si; nn < per_group; nn += ns) {
         const long long base = (((long long)g * per_group + nn) * C + c) * P;
         for (long long e = (long long)cpi * BN_THREADS + threadIdx.x; e < P; e += (long long)cp * BN_THREADS) {
@@ -127,8 +129,25 @@ bn_bwd_apply_k(float* __restrict__ dxe, const float* __restrict__ p, int C, long
             float v = k * (dxe[off] - m1 - hh * m2);
             if (relu && !(pv > 0.f)) v = 0.f;
             dxe[off] = v;
+            vs += v;
         }
     }
+    if (csum_part) {                              // per-channel sum of the result = the producing layer's bias gradient
+        double a = (double)vs, b = 0.0;
+        block_sum2(a, b);
+        if (threadIdx.x == 0) csum_part[(size_t)gc * chunks + chunk] = a;
+    }
+}
+
+// out[c] (+)= sum over groups and chunks of part[(g*C + c)*chunks + k]
+__global__ void __launch_bounds__(64)
+csum_fold_k(const double* __restrict__ part, int G, int C, int chunks, int accumulate, float* __restrict__ out) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double a = 0;
+    for (int g = 0; g < G; ++g)
+        for (int k = lane; k < chunks; k += VG_WAVE) a += part[((size_t)g * C + c) * chunks + k];
+    a = wave_sum(a);
+    if (lane == 0) out[c] = (accumulate ? out[c] : 0.f) + (float)a;
 }
 
 // chunks over the P positions of one sample (cp) and sample splits (ns): grid.x = cp * ns, sized so
@@ -214,15 +233,24 @@ extern "C" int vg_bn_bwd_reduce(const float* dxe, const float* p, int32_t N, int
 
 extern "C" int vg_bn_bwd_apply(float* dxe, const float* p, int32_t N, int32_t C, int64_t P, int32_t per_group,
                                int32_t relu, const float* gamma, const float* mean, const float* rstd,
-                               const double* sums, double count, float* dgamma_part, float* dbeta_part, void* stream) {
+                               const double* sums, double count, float* dgamma_part, float* dbeta_part,
+                               void* ws, float* chsum, int32_t chsum_accumulate, void* stream) {
     int rc = bn_args_ok("vg_bn_bwd_apply", dxe, N, C, P, per_group);
     if (rc) return rc;
     if (!p || !mean || !rstd || !sums || !dgamma_part || !dbeta_part || !(count > 0)) { vg_set_error("vg_bn_bwd_apply: bad argument"); return VG_ERR_ARG; }
+    if (chsum && !ws) { vg_set_error("vg_bn_bwd_apply: chsum needs the vg_bn_ws_bytes workspace"); return VG_ERR_ARG; }
     const int G = N / per_group;
     const BnPlan pl = plan_for(P, per_group, C, G);
+    double* csum_part = chsum ? (double*)ws : nullptr;
     vg_launch(bn_bwd_apply_k, dim3(pl.chunks(), C, G), dim3(BN_THREADS), 0, (hipStream_t)stream, dxe, p, (int)C, (long long)P,
-              (int)per_group, (int)relu, gamma, mean, rstd, sums, count, pl.cp, dgamma_part, dbeta_part);
-    return vg_check_launch("bn_bwd_apply");
+              (int)per_group, (int)relu, gamma, mean, rstd, sums, count, pl.cp, dgamma_part, dbeta_part, csum_part);
+    if ((rc = vg_check_launch("bn_bwd_apply"))) return rc;
+    if (chsum) {
+        vg_launch(csum_fold_k, dim3(C), dim3(64), 0, (hipStream_t)stream, (const double*)csum_part, G, (int)C, pl.chunks(),
+                  (int)chsum_accumulate, chsum);
+        return vg_check_launch("bn_bwd csum_fold");
+    }
+    return VG_OK;
 }
 
 namespace {

@@ -314,6 +314,15 @@ def _grad_buf(t):
     return None
 
 
+# per-channel sums of a data gradient that the kernel producing it already formed (keyed by the gradient's storage):
+# the next backward node takes its bias gradient from here instead of re-reading the whole tensor
+_CHSUM = {}
+
+
+def _chsum_key(t):
+    return (t.data_ptr(), tuple(t.shape))
+
+
 def bn_backward_(dxe, p, gamma, mean, rstd, relu, per_group, sync=None, beta=None):
     """In place: dxe (grad w.r.t. the normalised tensor) -> grad w.r.t. the stored pre-activation p.
     Returns (dgamma[C], dbeta[C]) summed over groups -- or (None, None) after adding them straight into
@@ -333,8 +342,11 @@ def bn_backward_(dxe, p, gamma, mean, rstd, relu, per_group, sync=None, beta=Non
         sums = sync(sums)
         count = count * sync.world_size
     parts = torch.empty((2, G, C), dtype=torch.float32, device=p.device)
+    chs = torch.empty(C, dtype=torch.float32, device=p.device)
     _call(p, 'vg_bn_bwd_apply', _p(dxe), _p(p), N, C, P, per_group, int(relu), _p(gamma), _p(mean), _p(rstd), _p(sums),
-             count, _p(parts[0]), _p(parts[1]))
+             count, _p(parts[0]), _p(parts[1]), _p(ws), _p(chs), 0)
+    _CHSUM.clear()
+    _CHSUM[_chsum_key(dxe)] = chs
     src = local if local is not None else sums      # data parallel: this rank's share (the gradient all-reduce sums them)
     gg, bg = _grad_buf(gamma), _grad_buf(beta)
     if gg is not None and bg is not None:
@@ -346,6 +358,12 @@ def bn_backward_(dxe, p, gamma, mean, rstd, relu, per_group, sync=None, beta=Non
 
 
 def channel_sum(x, out=None):
+    pre = _CHSUM.pop(_chsum_key(x), None)
+    if pre is not None and pre.device == x.device:         # already summed by the batch-norm backward that produced x
+        if out is not None:
+            out.add_(pre)
+            return None
+        return pre
     lib = _lib.get_lib()
     N, C = x.shape[0], x.shape[1]
     P = x[0, 0].numel()
@@ -373,6 +391,7 @@ class BnConvAct(torch.autograd.Function):
     def forward(ctx, p_in, weight, bias, gamma, beta, spec: ConvSpec, relu_in: bool, per_group: int,
                 input_is_data: bool, sync, packed=None):
         p_in = p_in.contiguous()
+        _CHSUM.clear()                                   # sums handed over between backward nodes never outlive a backward pass
         has_bn = gamma is not None
         scale = shift = mean = rstd = None
         with label(spec.name + '/fwd'):
