@@ -809,6 +809,10 @@ static int check_desc(const vg_conv_desc* d, const void* x, const void* w, const
     return VG_OK;
 }
 
+// vg_conv_mfma.hip: stride-1 3x3x3 layers on the matrix cores; -1 = geometry not covered
+int vg_corr3d_s1_mfma(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias, const float* in_scale,
+                      const float* in_shift, const float* mask_src, float* y, hipStream_t s);
+
 extern "C" int vg_corr3d(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias,
                          const float* in_scale, const float* in_shift, const float* mask_src, float* y, void* stream) {
     int rc = check_desc(d, x, wpk, y, "vg_corr3d");
@@ -836,6 +840,7 @@ extern "C" int vg_corr3d(const vg_conv_desc* d, const float* x, const float* wpk
     { int r_ = launch_corr_plane<COT, KD, KH, KW, S, TDt, THt, TW>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); \
       if (r_ >= 0) return r_; \
       return launch_corr<COT, KD, KH, KW, S, TDt, THt, TW>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); }
+    if (!getenv("VG_NO_S1M")) { int r_ = vg_corr3d_s1_mfma(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); if (r_ >= 0) return r_; }
 #define CORR_MFMA(KD, KH, KW, S) \
     if (d->CI > 8 && d->CO > 8 && !getenv("VG_NO_MFMA_CONV")) { int r_ = launch_corr_mfma<KD, KH, KW, S, 8>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); if (r_ >= 0) return r_; }
     if (k333 && d->stride == 1) CORR_MFMA(3, 3, 3, 1)
