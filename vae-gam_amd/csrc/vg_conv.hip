@@ -629,7 +629,7 @@ struct TconvParams {
 };
 
 template <int COT, int KD, int KH, int KW>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 tconv3d_s2_k(const float* __restrict__ x, const float* __restrict__ wpk, const float* __restrict__ bias,
              const float* __restrict__ in_scale, const float* __restrict__ in_shift,
              const float* __restrict__ mask_src, float* __restrict__ y, TconvParams p) {
