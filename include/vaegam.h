@@ -51,6 +51,15 @@ int vg_corr3d(const vg_conv_desc* d, const float* x, const float* wpk, const flo
  * the stride-2 Conv3d layers (autograd of :239,241). mask_src as above. */
 int vg_tconv3d_s2(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias,
                   const float* in_scale, const float* in_shift, const float* mask_src, float* y, void* stream);
+/* vg_tconv3d_s2 that ALSO accumulates the batch statistics the NEXT layer's BatchNorm3d needs (vae_reg_GP.py:216-218,
+ * 254-264: bnt3 after convt2, bnt5 after convt4) while the outputs are still in registers: per (group, channel) partial
+ * [sum, sum of squares] of relu?(y), one pair per wavefront, laid out for vg_bn_stats_from_parts:
+ *   stats_part[((g*CO + c)*chunks + k)*2 + {0,1}],  chunks = vg_tconv3d_s2_stats_chunks(d, stats_per_group).
+ * Saves the separate full-tensor read of vg_bn_stats. */
+int64_t vg_tconv3d_s2_stats_chunks(const vg_conv_desc* d, int32_t stats_per_group);
+int vg_tconv3d_s2_stats(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias,
+                        const float* in_scale, const float* in_shift, float* y, int32_t stats_per_group,
+                        int32_t stats_relu, double* stats_part, void* stream);
 
 /* weight gradient:  dw[cb][ca][k] = sum_{n,p} PB(b)[n][cb][p] * PA(a)[n][ca][p*stride + k - pad]
  * b: [N][CB][PD][PH][PW], a: [N][CA][AD][AH][AW] (zero outside).  For a Conv3d layer b = dy,
@@ -86,6 +95,12 @@ int vg_bn_stats(const float* x, int32_t N, int32_t C, int64_t P, int32_t per_gro
                 float* scale, float* shift, float* mean, float* rstd, void* stream);
 int vg_bn_finalize(const double* sums, int32_t G, int32_t C, const float* gamma, const float* beta,
                    float eps, float* scale, float* shift, float* mean, float* rstd, void* stream);
+/* vg_bn_stats from per-block partials another kernel produced (vg_tconv3d_s2_stats): fold + finalize.
+ * count = elements per (group, channel); ext_sums != NULL: write the raw [sum, sumsq, count] triples there and stop
+ * (data-parallel caller all-reduces, then vg_bn_finalize); else sums_ws (double[G*C*3]) is scratch. */
+int vg_bn_stats_from_parts(const double* part, int32_t G, int32_t C, int64_t chunks, double count,
+                           const float* gamma, const float* beta, float eps, double* ext_sums, double* sums_ws,
+                           float* scale, float* shift, float* mean, float* rstd, void* stream);
 
 /* batch-norm backward through h = relu?(p), xe = (h-mean)*rstd*gamma+beta, given dxe (in place):
  *   dgamma_part[g][c] = sum dxe*hhat, dbeta_part[g][c] = sum dxe,

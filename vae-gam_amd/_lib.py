@@ -33,6 +33,9 @@ _PROTOS = {
     'vg_last_error': (ctypes.c_char_p, []),
     'vg_corr3d': (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
     'vg_tconv3d_s2': (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
+    'vg_tconv3d_s2_stats_chunks': (i64, [ctypes.POINTER(ConvDesc), i32]),
+    'vg_tconv3d_s2_stats': (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+    'vg_bn_stats_from_parts': (ctypes.c_int, [vp, i32, i32, i64, f64, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),
     'vg_wgrad3d_ws_bytes': (i64, [ctypes.POINTER(WgradDesc)]),
     'vg_wgrad3d': (ctypes.c_int, [ctypes.POINTER(WgradDesc), vp, vp, vp, vp, vp, vp, i32, vp]),
     'vg_bn_ws_bytes': (i64, [i32, i32, i64, i32]),

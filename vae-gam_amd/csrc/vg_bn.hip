@@ -280,6 +280,18 @@ extern "C" int vg_channel_sum(const float* x, int32_t N, int32_t C, int64_t P, v
     return vg_check_launch("channel_sum fold");
 }
 
+extern "C" int vg_bn_stats_from_parts(const double* part, int32_t G, int32_t C, int64_t chunks, double count,
+                                      const float* gamma, const float* beta, float eps, double* ext_sums, double* sums_ws,
+                                      float* scale, float* shift, float* mean, float* rstd, void* stream) {
+    if (!part || G <= 0 || C <= 0 || chunks <= 0 || !(count > 0) || (!ext_sums && !sums_ws)) { vg_set_error("vg_bn_stats_from_parts: bad argument"); return VG_ERR_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    double* sums = ext_sums ? ext_sums : sums_ws;
+    vg_launch(bn_fold_k, dim3(G * C), dim3(64), 0, s, part, G * C, (int)chunks, count, 3, sums);
+    int rc = vg_check_launch("bn_fold(parts)");
+    if (rc || ext_sums) return rc;
+    return vg_bn_finalize(sums, G, C, gamma, beta, eps, scale, shift, mean, rstd, stream);
+}
+
 namespace {
 // dgamma[c] (+)= sum_g sums[g][c][1], dbeta[c] (+)= sum_g sums[g][c][0]
 __global__ void __launch_bounds__(64)

@@ -632,7 +632,8 @@ template <int COT, int KD, int KH, int KW>
 __global__ void __launch_bounds__(256, 4)
 tconv3d_s2_k(const float* __restrict__ x, const float* __restrict__ wpk, const float* __restrict__ bias,
              const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-             const float* __restrict__ mask_src, float* __restrict__ y, TconvParams p) {
+             const float* __restrict__ mask_src, float* __restrict__ y, TconvParams p,
+             double* __restrict__ stats_part, int stats_relu, int stats_pg) {
     constexpr int KVOL = KD * KH * KW;
     constexpr int MD = (KD + 1) / 2, MH = (KH + 1) / 2, MW = (KW + 1) / 2;
     const vg_conv_desc& d = p.d;
@@ -645,7 +646,10 @@ tconv3d_s2_k(const float* __restrict__ x, const float* __restrict__ wpk, const f
     const int co0 = blockIdx.z * COT;
     const int jwl = tid % p.TJW; const int jhl = (tid / p.TJW) % p.TJH; const int jdl = tid / (p.TJW * p.TJH);
     const int jd = tdi * p.TJD + jdl, jh = thi * p.TJH + jhl, jw = twi * p.TJW + jwl;
-    if (jdl >= p.TJD || jd >= p.JD || jh >= p.JH || jw >= p.JW) return;           // no barriers in this kernel
+    // threads past the tile / the volume stay alive (clamped loads, no stores): the optional statistics epilogue reduces
+    // over whole wavefronts
+    const bool active = !(jdl >= p.TJD || jd >= p.JD || jh >= p.JH || jw >= p.JW);
+    if (!active && stats_part == nullptr) return;                                  // no barriers in this kernel
 
     // input i = j - m per dim: clamped offsets + validity, shared by all channels
     int roff[MD][MH]; bool rok[MD][MH];
@@ -750,10 +754,13 @@ tconv3d_s2_k(const float* __restrict__ x, const float* __restrict__ wpk, const f
             }
         }
     }
+    float st_s[COT], st_q[COT];                       // optional: sum / sum of squares of relu?(y) per channel (next layer's BN)
+#pragma unroll
+    for (int co = 0; co < COT; ++co) { st_s[co] = 0.f; st_q[co] = 0.f; }
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) {
         const int od = 2 * jd + rd - d.pad_d;
-        if (od < 0 || od >= d.OD) continue;
+        if (!active || od < 0 || od >= d.OD) continue;
 #pragma unroll
         for (int rh = 0; rh < 2; ++rh) {
             const int oh = 2 * jh + rh - d.pad_h;
@@ -767,9 +774,29 @@ tconv3d_s2_k(const float* __restrict__ x, const float* __restrict__ wpk, const f
                     const int ow = 2 * jw + rw - d.pad_w;
                     if (ow >= 0 && ow < d.OW) {
                         const float v = acc[rd][rh][rw][co];
-                        y[base + ow] = (v == -__builtin_inff()) ? 0.f : v + bv;
+                        const float o = (v == -__builtin_inff()) ? 0.f : v + bv;
+                        y[base + ow] = o;
+                        const float h = stats_relu ? vg_max(o, 0.f) : o;
+                        st_s[co] += h; st_q[co] = fmaf(h, h, st_q[co]);
                     }
                 }
+            }
+        }
+    }
+    if (stats_part) {
+        // one partial per WAVEFRONT (no barrier): part[((g*CO + c)*chunks + chunk)*2 + {0,1}], chunk = ((n % pg)*tiles + tile)*nw + wave
+        const int lane = tid % VG_WAVE, wv = tid / VG_WAVE, nw = blockDim.x / VG_WAVE;
+        const int g = n / stats_pg;
+        const size_t chunks = (size_t)stats_pg * gridDim.x * nw;
+        const size_t chunk = ((size_t)(n % stats_pg) * gridDim.x + blockIdx.x) * nw + wv;
+#pragma unroll
+        for (int co = 0; co < COT; ++co) {
+            float a = st_s[co], b = st_q[co];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+            if (lane == 0) {
+                double* dst = stats_part + (((size_t)g * CO + co0 + co) * chunks + chunk) * 2;
+                dst[0] = (double)a; dst[1] = (double)b;
             }
         }
     }
@@ -777,7 +804,8 @@ tconv3d_s2_k(const float* __restrict__ x, const float* __restrict__ wpk, const f
 
 template <int COT, int KD, int KH, int KW>
 int launch_tconv(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias, const float* in_scale,
-                 const float* in_shift, const float* mask_src, float* y, hipStream_t s) {
+                 const float* in_shift, const float* mask_src, float* y, hipStream_t s,
+                 double* stats_part = nullptr, int stats_relu = 0, int stats_pg = 1, int64_t* chunks_only = nullptr) {
     TconvParams p; p.d = *d;
     p.JD = (d->OD + d->pad_d + 1) / 2; p.JH = (d->OH + d->pad_h + 1) / 2; p.JW = (d->OW + d->pad_w + 1) / 2;
     p.TJW = p.JW < 32 ? p.JW : 32;
@@ -790,8 +818,9 @@ int launch_tconv(const vg_conv_desc* d, const float* x, const float* wpk, const 
     if (d->CO % COT) { vg_set_error("tconv3d_s2: CO=%d not a multiple of %d", d->CO, COT); return VG_ERR_UNSUPPORTED; }
     const int threads = vg_cdiv(p.TJW * p.TJH * p.TJD, VG_WAVE) * VG_WAVE;
     dim3 grid(p.tilesW * p.tilesH * p.tilesD, d->N, d->CO / COT);
+    if (chunks_only) { *chunks_only = (int64_t)stats_pg * grid.x * (threads / VG_WAVE); return VG_OK; }
     vg_launch(tconv3d_s2_k<COT, KD, KH, KW>, grid, dim3(threads), 0, s,
-              x, wpk, bias, in_scale, in_shift, mask_src, y, p);
+              x, wpk, bias, in_scale, in_shift, mask_src, y, p, stats_part, stats_relu, stats_pg);
     return vg_check_launch("tconv3d_s2");
 }
 
@@ -865,19 +894,13 @@ extern "C" int vg_corr3d(const vg_conv_desc* d, const float* x, const float* wpk
     return VG_ERR_UNSUPPORTED;
 }
 
-extern "C" int vg_tconv3d_s2(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias,
-                             const float* in_scale, const float* in_shift, const float* mask_src, float* y, void* stream) {
-    int rc = check_desc(d, x, wpk, y, "vg_tconv3d_s2");
-    if (rc) return rc;
-    if (d->stride != 2) { vg_set_error("vg_tconv3d_s2: stride must be 2"); return VG_ERR_ARG; }
-    if ((in_scale == nullptr) != (in_shift == nullptr) || (in_scale && d->per_group <= 0)) {
-        vg_set_error("vg_tconv3d_s2: in_scale/in_shift/per_group inconsistent"); return VG_ERR_ARG;
-    }
-    hipStream_t s = (hipStream_t)stream;
+static int tconv_dispatch(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias, const float* in_scale,
+                          const float* in_shift, const float* mask_src, float* y, hipStream_t s,
+                          double* stats_part, int stats_relu, int stats_pg, int64_t* chunks_only) {
     const long long pos = (long long)d->N * d->OD * d->OH * d->OW;
     const bool small = pos * d->CO < (long long)8 * 1024 * 1024;
 #define TCONV(COT, KD, KH, KW) \
-    return launch_tconv<COT, KD, KH, KW>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s)
+    return launch_tconv<COT, KD, KH, KW>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s, stats_part, stats_relu, stats_pg, chunks_only)
     if (d->KD == 3 && d->KH == 3 && d->KW == 3) {
         if (d->CO % 8 == 0 && !small) TCONV(8, 3, 3, 3);
         if (d->CO % 4 == 0 && small) TCONV(4, 3, 3, 3);
@@ -887,4 +910,40 @@ extern "C" int vg_tconv3d_s2(const vg_conv_desc* d, const float* x, const float*
 #undef TCONV
     vg_set_error("vg_tconv3d_s2: no kernel instance for CO=%d k=%dx%dx%d", d->CO, d->KD, d->KH, d->KW);
     return VG_ERR_UNSUPPORTED;
+}
+
+static int tconv_check(const vg_conv_desc* d, const float* x, const float* wpk, const float* in_scale, const float* in_shift,
+                       const float* y) {
+    int rc = check_desc(d, x, wpk, y, "vg_tconv3d_s2");
+    if (rc) return rc;
+    if (d->stride != 2) { vg_set_error("vg_tconv3d_s2: stride must be 2"); return VG_ERR_ARG; }
+    if ((in_scale == nullptr) != (in_shift == nullptr) || (in_scale && d->per_group <= 0)) {
+        vg_set_error("vg_tconv3d_s2: in_scale/in_shift/per_group inconsistent"); return VG_ERR_ARG;
+    }
+    return VG_OK;
+}
+
+extern "C" int vg_tconv3d_s2(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias,
+                             const float* in_scale, const float* in_shift, const float* mask_src, float* y, void* stream) {
+    int rc = tconv_check(d, x, wpk, in_scale, in_shift, y);
+    if (rc) return rc;
+    return tconv_dispatch(d, x, wpk, bias, in_scale, in_shift, mask_src, y, (hipStream_t)stream, nullptr, 0, 1, nullptr);
+}
+
+extern "C" int64_t vg_tconv3d_s2_stats_chunks(const vg_conv_desc* d, int32_t stats_per_group) {
+    if (!d || stats_per_group <= 0 || d->N % stats_per_group) return -1;
+    int64_t chunks = 0;
+    float dummy;
+    int rc = tconv_dispatch(d, &dummy, &dummy, nullptr, nullptr, nullptr, nullptr, &dummy, nullptr, nullptr, 0, stats_per_group, &chunks);
+    return rc ? -1 : chunks;
+}
+
+extern "C" int vg_tconv3d_s2_stats(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias,
+                                   const float* in_scale, const float* in_shift, float* y, int32_t stats_per_group,
+                                   int32_t stats_relu, double* stats_part, void* stream) {
+    int rc = tconv_check(d, x, wpk, in_scale, in_shift, y);
+    if (rc) return rc;
+    if (!stats_part || stats_per_group <= 0 || d->N % stats_per_group) { vg_set_error("vg_tconv3d_s2_stats: bad statistics arguments"); return VG_ERR_ARG; }
+    return tconv_dispatch(d, x, wpk, bias, in_scale, in_shift, nullptr, y, (hipStream_t)stream, stats_part, stats_relu,
+                          stats_per_group, nullptr);
 }

@@ -212,8 +212,15 @@ def _conv_desc(N, ci, co, isz, osz, k, stride, pad, relu_in, per_group):
                     pad[0], pad[1], pad[2], int(relu_in), int(per_group))
 
 
-def conv_forward(x, wpk, bias, spec: ConvSpec, relu_in=False, scale=None, shift=None, per_group=1):
-    """Layer forward: y = conv/convT(P(x)) + bias, y is the pre-activation."""
+# batch statistics of a layer output that the kernel producing it already accumulated (keyed by the output's storage):
+# (partials, chunks, relu, per_group) for the NEXT layer's bn_stats
+_STATS = {}
+
+
+def conv_forward(x, wpk, bias, spec: ConvSpec, relu_in=False, scale=None, shift=None, per_group=1, next_bn=None):
+    """Layer forward: y = conv/convT(P(x)) + bias, y is the pre-activation.
+    next_bn = per_group of the BatchNorm3d that consumes relu(y): the stride-2 transposed-conv kernel then also leaves the
+    statistics partials for it (no separate pass over y)."""
     lib = _lib.get_lib()
     N = x.shape[0]
     isz = tuple(x.shape[2:]); osz = spec.out_size(isz)
@@ -229,7 +236,16 @@ def conv_forward(x, wpk, bias, spec: ConvSpec, relu_in=False, scale=None, shift=
         _call(x, 'vg_corr3d', ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(scale), _p(shift), None, _p(y))
     else:
         d = _conv_desc(N, spec.ci, spec.co, isz, osz, spec.k, 2, spec.pad, relu_in, per_group)
-        _call(x, 'vg_tconv3d_s2', ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(scale), _p(shift), None, _p(y))
+        if next_bn:
+            chunks = lib.size('vg_tconv3d_s2_stats_chunks', ctypes.byref(d), int(next_bn))
+            G = N // int(next_bn)
+            part = torch.empty(G * spec.co * chunks * 2, dtype=torch.float64, device=x.device)
+            _call(x, 'vg_tconv3d_s2_stats', ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(scale), _p(shift), _p(y), int(next_bn), 1,
+                     _p(part))
+            _STATS.clear()
+            _STATS[_chsum_key(y)] = (part, chunks, True, int(next_bn))
+        else:
+            _call(x, 'vg_tconv3d_s2', ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(scale), _p(shift), None, _p(y))
     return y
 
 
@@ -292,8 +308,23 @@ def bn_stats(x, gamma, beta, relu, per_group, sync=None):
     N, C = x.shape[0], x.shape[1]
     P = x[0, 0].numel()
     G = N // per_group
-    ws = _bn_ws(x, N, C, P, per_group)
     out = torch.empty((4, G * C), dtype=torch.float32, device=x.device)
+    pre = _STATS.pop(_chsum_key(x), None)
+    if pre is not None and pre[2] == bool(relu) and pre[3] == per_group and pre[0].device == x.device:
+        part, chunks = pre[0], pre[1]                      # accumulated by the kernel that wrote x
+        sums = torch.empty((G * C, 3), dtype=torch.float64, device=x.device)
+        count = float(per_group * P)
+        if sync is None:
+            _call(x, 'vg_bn_stats_from_parts', _p(part), G, C, chunks, count, _p(gamma), _p(beta), BN_EPS, None, _p(sums),
+                     _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]))
+        else:
+            _call(x, 'vg_bn_stats_from_parts', _p(part), G, C, chunks, count, _p(gamma), _p(beta), BN_EPS, _p(sums), None,
+                     None, None, None, None)
+            sums = sync(sums)
+            _call(x, 'vg_bn_finalize', _p(sums), G, C, _p(gamma), _p(beta), BN_EPS, _p(out[0]), _p(out[1]), _p(out[2]),
+                     _p(out[3]))
+        return out[0], out[1], out[2], out[3]
+    ws = _bn_ws(x, N, C, P, per_group)
     if sync is None:
         _call(x, 'vg_bn_stats', _p(_chk(x)), N, C, P, per_group, int(relu), _p(gamma), _p(beta), BN_EPS, _p(ws), None,
                  _p(out[0]), _p(out[1]), _p(out[2]), _p(out[3]))
@@ -389,7 +420,7 @@ class BnConvAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, p_in, weight, bias, gamma, beta, spec: ConvSpec, relu_in: bool, per_group: int,
-                input_is_data: bool, sync, packed=None):
+                input_is_data: bool, sync, packed=None, next_bn=None):
         p_in = p_in.contiguous()
         _CHSUM.clear()                                   # sums handed over between backward nodes never outlive a backward pass
         has_bn = gamma is not None
@@ -398,7 +429,7 @@ class BnConvAct(torch.autograd.Function):
             if has_bn:
                 scale, shift, mean, rstd = bn_stats(p_in, gamma, beta, relu_in, per_group, sync)
             wf = packed.get(spec.name, 'fwd') if packed is not None else pack_weight(weight, spec, 'fwd')
-            y = conv_forward(p_in, wf, bias, spec, relu_in, scale, shift, per_group)
+            y = conv_forward(p_in, wf, bias, spec, relu_in, scale, shift, per_group, next_bn)
         ctx.spec, ctx.relu_in, ctx.per_group, ctx.input_is_data, ctx.sync, ctx.has_bn = \
             spec, relu_in, per_group, input_is_data, sync, has_bn
         ctx.save_for_backward(p_in, weight, gamma, beta, scale, shift, mean, rstd)
@@ -445,7 +476,7 @@ class BnConvAct(torch.autograd.Function):
                 dbeta = (weight.sum((2, 3, 4)) * db.view(-1, 1)).sum(0)
             else:
                 dw = conv_weight_grad(p_in, dy, spec, relu_in, None, None, per_group, out=wg)
-            return None, dw, db, dgamma, dbeta, None, None, None, None, None, None
+            return None, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
         if not overlap:
             dw = conv_weight_grad(p_in, dy, spec, relu_in, scale, shift, per_group, out=wg)
         wb = ctx.packed.get(spec.name, 'bwd') if ctx.packed is not None else pack_weight(weight, spec, 'bwd')
@@ -455,13 +486,14 @@ class BnConvAct(torch.autograd.Function):
             dgamma, dbeta = bn_backward_(dp, p_in, gamma, mean, rstd, relu_in, per_group, ctx.sync, beta)
         else:
             dp = conv_backward_data(dy, wb, spec, in_size, p_in if relu_in else None)
-        return dp, dw, db, dgamma, dbeta, None, None, None, None, None, None
+        return dp, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-def bn_conv_act(p_in, weight, bias, gamma, beta, spec, relu_in, per_group=None, input_is_data=False, sync=None, packed=None):
+def bn_conv_act(p_in, weight, bias, gamma, beta, spec, relu_in, per_group=None, input_is_data=False, sync=None, packed=None,
+                next_bn=None):
     if per_group is None:
         per_group = p_in.shape[0]
-    return BnConvAct.apply(p_in, weight, bias, gamma, beta, spec, relu_in, per_group, input_is_data, sync, packed)
+    return BnConvAct.apply(p_in, weight, bias, gamma, beta, spec, relu_in, per_group, input_is_data, sync, packed, next_bn)
 
 
 class GamElbo(torch.autograd.Function):

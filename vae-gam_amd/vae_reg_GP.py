@@ -248,9 +248,9 @@ class VAE(nn.Module):
         h = la(self.fc7, la(self.fc6, la(self.fc5, z, True), True), True)
         p = la(self.fc8, h, False).view(-1, 2 * self.nf, *self.geom.dec_seed)   # ReLU applied by convt1's loader
         p = ops.bn_conv_act(p, self.convt1.weight, self.convt1.bias, self.bnt1.weight, self.bnt1.bias, dsp[0], True, per_group, False, s, self._packed)
-        p = ops.bn_conv_act(p, self.convt2.weight, self.convt2.bias, None, None, dsp[1], True, per_group, False, s, self._packed)
+        p = ops.bn_conv_act(p, self.convt2.weight, self.convt2.bias, None, None, dsp[1], True, per_group, False, s, self._packed, per_group)   # + bnt3's statistics
         p = ops.bn_conv_act(p, self.convt3.weight, self.convt3.bias, self.bnt3.weight, self.bnt3.bias, dsp[2], True, per_group, False, s, self._packed)
-        p = ops.bn_conv_act(p, self.convt4.weight, self.convt4.bias, None, None, dsp[3], True, per_group, False, s, self._packed)
+        p = ops.bn_conv_act(p, self.convt4.weight, self.convt4.bias, None, None, dsp[3], True, per_group, False, s, self._packed, per_group)   # + bnt5's statistics
         p = ops.bn_conv_act(p, self.convt5.weight, self.convt5.bias, self.bnt5.weight, self.bnt5.bias, dsp[4], True, per_group, False, s, self._packed)
         return p.reshape(p.shape[0], self.img_dim)
 
