@@ -982,6 +982,8 @@ int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const fl
 #undef VG_PICK
     int per_cu = vg_blocks_per_cu((const void*)kern, 256, fl * sizeof(float));   // persistent grid == resident blocks
     if (per_cu > 8) per_cu = 8;
+    { static const int cap_blocks = getenv("VG_WGRAD_BLOCKS_PER_CU") ? atoi(getenv("VG_WGRAD_BLOCKS_PER_CU")) : 0;
+      if (cap_blocks > 0 && per_cu > cap_blocks) per_cu = cap_blocks; }
     int grid = 256 * per_cu; if (grid > p.items) grid = p.items;
     const int len = d->CB * CA * KVOL;
     if (ws_bytes_only) { *ws_bytes_only = (int64_t)grid * len * sizeof(float); return VG_OK; }

@@ -59,7 +59,8 @@ def _call(t, fn, *args):
 # next layer's backward waits for).  Measured on MI355X at batch 32 (hipGraph replay): 7.75 ms/step with the side
 # stream vs 7.29 ms without -- the persistent weight-gradient blocks hold the LDS of every CU, so the chains do not
 # overlap and the extra stream joins only add boundaries.  Left off; kept because it may pay at smaller batches.
-SIDE_STREAM = False
+import os as _os
+SIDE_STREAM = bool(int(_os.environ.get('VG_SIDE_STREAM', '0')))
 _SIDE = {}
 
 
