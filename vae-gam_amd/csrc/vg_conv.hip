@@ -243,6 +243,7 @@ struct CorrPlaneParams {
     int LD;                     // input planes per chunk-channel
     int CCH;                    // channels per chunk
     int ch_floats;              // LDS floats per channel (LD*IH*IW rounded up)
+    int nbuf;                   // 2: the next chunk's planes are DMA'd behind this chunk's FMAs (one barrier per chunk)
 };
 constexpr int PLANE_SLACK = 8;  // floats in front of the LDS buffer: a window may start at iw = -pad
 
@@ -304,24 +305,41 @@ corr3d_plane_k(const float* __restrict__ x, const float* __restrict__ wpk, const
     const float lo = d.relu_in ? 0.f : -__builtin_inff();
     const size_t vol = (size_t)plane * d.ID;
     const float* __restrict__ xsrc = x + (size_t)n * d.CI * vol + (size_t)pl_lo * plane;
-    for (int c0 = 0; c0 < d.CI; c0 += p.CCH) {
+    auto stage = [&](int c0, float* buf) {
         const int cc = min(p.CCH, d.CI - c0);
-        __syncthreads();                                  // previous chunk fully consumed
         for (int c = 0; c < cc; ++c) {
             const float* src = xsrc + (size_t)(c0 + c) * vol;
-            float* dst = lds + c * p.ch_floats + dst0;
+            float* dst = buf + c * p.ch_floats + dst0;
             for (int o = wave * VG_WAVE; o < nfl; o += blockDim.x)
                 if (o + lane < nfl) vg_dma4(src + o + lane, dst + o);
         }
-        vg_dma_wait();
-        __syncthreads();
+    };
+    const int buf_floats = p.CCH * p.ch_floats;
+    if (p.nbuf == 2) stage(0, lds);
+    int kchunk = 0;
+    for (int c0 = 0; c0 < d.CI; c0 += p.CCH, ++kchunk) {
+        const int cc = min(p.CCH, d.CI - c0);
+        const float* cur = lds;
+        if (p.nbuf == 2) {
+            // this chunk's DMAs (issued during the previous chunk's FMAs) have landed; every wave is past the previous
+            // chunk, so the other buffer is free for the next one
+            vg_dma_wait();
+            __syncthreads();
+            cur = lds + (kchunk & 1) * buf_floats;
+            if (c0 + p.CCH < d.CI) stage(c0 + p.CCH, lds + ((kchunk + 1) & 1) * buf_floats);
+        } else {
+            __syncthreads();                              // previous chunk fully consumed
+            stage(c0, lds);
+            vg_dma_wait();
+            __syncthreads();
+        }
         if (active) {
             for (int c = 0; c < cc; ++c) {
                 const int ci = c0 + c;
                 const float* __restrict__ wc = wpk + (size_t)ci * KVOL * CO + co0;
                 float sc = 1.f, sh = 0.f;
                 if (in_scale != nullptr) { sc = in_scale[g * d.CI + ci]; sh = in_shift[g * d.CI + ci]; }
-                const float* tl = lds + c * p.ch_floats;
+                const float* tl = cur + c * p.ch_floats;
 #pragma unroll
                 for (int dz = 0; dz < RD; ++dz) {
 #pragma unroll
@@ -428,11 +446,19 @@ int launch_corr_plane(const vg_conv_desc* d, const float* x, const float* wpk, c
     p.TD = td; p.LD = (td * TDt - 1) * S + KD;
     p.tilesD = vg_cdiv(gd, p.TD);
     p.ch_floats = ((p.LD * plane + 63) / 64) * 64 + 64;  // slot per channel: whole 256-byte DMA groups + slack for window over-reads
-    int cch = (int)((budget - 64) / ((size_t)p.ch_floats * sizeof(float)));
+    // Optional (VG_PLANE_NBUF=2): two buffers, the next chunk in flight behind this chunk's FMAs, one barrier per chunk.
+    // Measured on MI355X: no gain where the chunk is small (convt3/convt4: 3 blocks per CU already hide the fill) and a
+    // loss where it doubles a 25 KB slot (convt5 forward 244 -> 341 us: only two 52 KB blocks fit a CU). Off by default.
+    static const int nbuf_env = getenv("VG_PLANE_NBUF") ? atoi(getenv("VG_PLANE_NBUF")) : 0;
+    const size_t budget2 = 52 * 1024;
+    p.nbuf = (nbuf_env == 2 && d->CI > 1 && 2 * (size_t)p.ch_floats * sizeof(float) + (PLANE_SLACK + 64) * sizeof(float) <= budget2) ? 2 : 1;
+    const size_t bud = p.nbuf == 2 ? budget2 : budget;
+    int cch = (int)((bud - (PLANE_SLACK + 64) * sizeof(float)) / ((size_t)p.ch_floats * sizeof(float) * p.nbuf));
     if (cch < 1) cch = 1;
     if (cch > d->CI) cch = d->CI;
+    if (p.nbuf == 2 && cch >= d->CI) { p.nbuf = 1; }      // everything fits one chunk: nothing to overlap
     p.CCH = cch;
-    const size_t shmem = (size_t)p.ch_floats * cch * sizeof(float) + (PLANE_SLACK + 64) * sizeof(float);
+    const size_t shmem = (size_t)p.ch_floats * cch * p.nbuf * sizeof(float) + (PLANE_SLACK + 64) * sizeof(float);
     if (d->CO % COT) { vg_set_error("corr3d: CO=%d not a multiple of %d", d->CO, COT); return VG_ERR_UNSUPPORTED; }
     const int threads = vg_cdiv(p.TWG * p.TH * p.TD, VG_WAVE) * VG_WAVE;
     dim3 grid(p.tilesD, d->N, d->CO / COT);
