@@ -524,6 +524,12 @@ class VAE(nn.Module):
                 g['p'].copy_(p0); g['m'].copy_(m0); g['v'].copy_(v0)
             self.optimizer.step_count = step0
             torch.cuda.set_rng_state(rng, x.device)
+        if self.dp is not None:
+            # every rank must make the same choice (a graph replays its collectives, an eager rank issues them one by one)
+            bad = torch.tensor([0.0 if self._graphs[key] is not False else 1.0], device=x.device)
+            if float(self.dp.allreduce_sum_(bad).item()) > 0 and self._graphs[key] is not False:
+                warnings.warn('hipGraph capture failed on another rank; all ranks launch eagerly')
+                self._graphs[key] = False
         return self._graphs[key]
 
     def train_epoch(self, train_loader):
