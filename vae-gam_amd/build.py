@@ -27,10 +27,26 @@ def up_to_date():
 
 
 def build_hip(force=False, verbose=True):
+    """One hipcc -c per source (in parallel: vg_wgrad.hip alone is ~3 minutes of template instances), then one link."""
     if not force and up_to_date():
         return OUT
-    cmd = [hipcc_path(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-           '-Wno-unused-result'] + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', OUT]
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = hipcc_path()
+    objdir = os.path.join(HERE, '_obj')
+    os.makedirs(objdir, exist_ok=True)
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + '.o')
+        cmd = [hipcc] + flags + ['-c', os.path.join(CSRC, src), '-o', obj]
+        if verbose:
+            print('[vae_gam_amd.build]', ' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, '--offload-arch=gfx950', '-fPIC', '-shared'] + objs + ['-o', OUT]
     if verbose:
         print('[vae_gam_amd.build]', ' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
