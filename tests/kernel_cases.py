@@ -205,6 +205,33 @@ def run_linear_case(dev, B=24, fin=40, fout=17, seed=0):
             np.testing.assert_allclose(lay.bias.grad.cpu().numpy() - off, ref.bias.grad.numpy(), rtol=1e-4, atol=1e-5)
 
 
+def run_fused_stats_case(dev, spec, isz, groups=2, per_group=3, seed=0):
+    """Transposed-conv forward that also leaves the next BatchNorm's statistics == a separate bn_stats pass over its output;
+    bn_backward_'s fused per-channel sum == channel_sum of its result."""
+    g = torch.Generator().manual_seed(seed)
+    N = groups * per_group
+    x = torch.randn(N, spec.ci, *isz, generator=g).to(dev)
+    w = (0.2 * torch.randn(spec.ci, spec.co, *spec.k, generator=g)).to(dev)
+    b = torch.randn(spec.co, generator=g).to(dev)
+    gamma = (1 + 0.1 * torch.randn(spec.co, generator=g)).to(dev); beta = (0.1 * torch.randn(spec.co, generator=g)).to(dev)
+    wf = ops.pack_weight(w, spec, 'fwd')
+    y = ops.conv_forward(x, wf, b, spec, True, None, None, per_group, next_bn=per_group)
+    assert ops._STATS, 'the stride-2 transposed-conv path must leave statistics partials'
+    fused = [t.clone() for t in ops.bn_stats(y, gamma, beta, True, per_group)]
+    assert not ops._STATS
+    plain = ops.bn_stats(y, gamma, beta, True, per_group)
+    for a_, b_, nm in zip(fused, plain, ('scale', 'shift', 'mean', 'rstd')):
+        np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=nm)
+    # fused bias-gradient sum of the batch-norm backward
+    dxe = torch.randn(y.shape, generator=g).to(dev)
+    ops.bn_backward_(dxe, y, gamma, plain[2], plain[3], True, per_group)
+    pre = ops._CHSUM.get(ops._chsum_key(dxe))
+    assert pre is not None
+    want = dxe.sum((0, 2, 3, 4))
+    np.testing.assert_allclose(pre.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(want.abs().max()))
+    ops._CHSUM.clear()
+
+
 def run_adam_case(dev, dtype, n=5000, steps=3, seed=0):
     g = torch.Generator().manual_seed(seed)
     p0 = torch.randn(n, generator=g, dtype=dtype)

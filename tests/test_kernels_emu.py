@@ -49,6 +49,11 @@ def test_first_layer_input_is_data():
     K.run_layer_case('cpu', name, spec, isz, with_bn=True, relu_in=False, groups=1, input_is_data=True, seed=5)
 
 
+def test_fused_bn_statistics_and_bias_sum():
+    K.run_fused_stats_case('cpu', K.LAYERS[8][1], K.LAYERS[8][2])        # convt4-shaped (5x3x3, stride 2)
+    K.run_fused_stats_case('cpu', K.LAYERS[6][1], K.LAYERS[6][2], seed=1)
+
+
 def test_gam_elbo():
     K.run_gam_case('cpu', C=3, B=3, V=1500)
 

@@ -54,6 +54,12 @@ def test_layer_full_geometry(idx):
                      groups=2 if spec.kind == 'convt' else 1, seed=7 + idx, tol=5e-4)
 
 
+def test_fused_bn_statistics_and_bias_sum():
+    K.run_fused_stats_case('cuda', K.LAYERS[8][1], K.LAYERS[8][2])        # convt4-shaped (5x3x3, stride 2)
+    K.run_fused_stats_case('cuda', K.LAYERS[6][1], K.LAYERS[6][2], seed=1)
+    K.run_fused_stats_case('cuda', K.LAYERS[8][1], (18, 23, 16), groups=2, per_group=4, seed=2)
+
+
 def test_gam_elbo():
     K.run_gam_case('cuda', C=3, B=3, V=1500)
     K.run_gam_case('cuda', C=8, B=4, V=70315, seed=4)
