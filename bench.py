@@ -214,7 +214,7 @@ def main():
             'metric': 'fMRI volumes/sec/train-step (41x49x35)', 'value': round(value, 1), 'unit': 'volumes/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: synthetic checker control (Large3), %d subjects x 98 volumes '
+            'config': {'workload': ('BASELINE configs[1]' if (B, C) == (32, 3) else 'BASELINE configs[2]' if (B, C) == (64, 8) else 'custom') + ': synthetic checker control (Large3), %d subjects x 98 volumes '
                                    '41x49x35, %d covariates, batch %d per GPU, full train step (fwd+bwd+Adam), '
                                    'gain/GP algebra on device in fp64, %s' % (a.subjects, C, B, 'hipGraph replay' if graphed else 'eager launches'),
                        'global_batch': B * world, 'covariates': C, 'parallelism': 'dp%d' % world},
