@@ -46,13 +46,26 @@ corr3d_s1m_k(const float* __restrict__ x, const float* __restrict__ wpk, const f
 
     for (int i = tid; i < p.lds_floats; i += blockDim.x) lds[i] = 0.f;       // halo cells are never written again: they stay zero
     __syncthreads();
-    // ---- weight image wl[ci][kd*3+kh][kw'][row]  (zero where a row has no weight for that kw')
-    for (int i = tid; i < CI * 9 * 64; i += blockDim.x) {
-        const int row = i & 15, kwp = (i >> 4) & 3, r2 = i >> 6;
-        const int kk = r2 % 9, ci = r2 / 9;
-        const int co = TOEP ? (row & 7) : row;
-        const int kw = TOEP ? kwp - (row >> 3) : kwp;
-        lds[i] = (kw >= 0 && kw < 3 && co < CO) ? wpk[((size_t)ci * 27 + kk * 3 + kw) * CO + co] : 0.f;
+    // ---- weight image wl[ci][kd*3+kh][kw'][row]  (zero where a row has no weight for that kw').  Gathers are issued in
+    //      batches of 8 before their LDS writes: one load -> wait -> write per iteration costs a full memory latency each
+    //      (36 of them for 16 channels was ~20 us of every launch).
+    {
+        const int nel = CI * 9 * 64;
+        for (int i0 = tid; i0 < nel; i0 += 8 * 256) {
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256;
+                const int row = i & 15, kwp = (i >> 4) & 3, r2 = i >> 6;
+                const int kk = r2 % 9, ci = r2 / 9;
+                const int co = TOEP ? (row & 7) : row;
+                const int kw = TOEP ? kwp - (row >> 3) : kwp;
+                const bool ok = i < nel && kw >= 0 && kw < 3 && co < CO;
+                wv[u] = ok ? wpk[((size_t)ci * 27 + kk * 3 + kw) * CO + co] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + u * 256 < nel) lds[i0 + u * 256] = wv[u];
+        }
     }
     // ---- staging geometry of this lane: cell q*64 + lane of a plane image -> (row, column)
     int srcoff[QMAX], rowq[QMAX];
@@ -208,9 +221,12 @@ int launch_s1m(const vg_conv_desc* d, const float* x, const float* wpk, const fl
             const size_t fl = wfl + (size_t)p.cc * LD * Q * 64 + 64;
             if (fl * 4 > budget) continue;
             const long pos = (long)td * th * PR;
-            // prefer more positions per tile, but never a tile that leaves the last depth block mostly empty
+            // prefer more positions per tile, but never a tile that leaves the last depth block mostly empty -- and never
+            // fewer items than CUs while a smaller tile would still give every wave a group
             const double util = ((double)d->OD / (((d->OD + td - 1) / td) * td)) * ((double)d->OH / (nb * th));
-            const long score = (long)(pos * util);
+            const long items = (long)d->N * ((d->OD + td - 1) / td) * nb;
+            const double fill = items >= 256 ? 1.0 : (double)items / 256.0;
+            const long score = (long)(pos * util * fill * fill);
             if (score > best_pos) { best_pos = score; best_td = td; best_th = th; }
             break;                                                        // smaller th for this td only lowers the score
         }
@@ -218,6 +234,9 @@ int launch_s1m(const vg_conv_desc* d, const float* x, const float* wpk, const fl
     p.TD = best_td; p.TH = best_th; p.LD = p.TD + 2; p.LR = p.TH + 2;
     p.Q = (p.LR * p.RWP + 63) / 64; p.PLP = p.Q * 64; p.CHP = p.LD * p.PLP;
     p.t_off = (int)wfl;
+    // as many channels per chunk as LDS holds (one fill + one barrier pair per chunk: the small layers then stage once per item)
+    for (int cc = d->CI; cc > p.cc; cc = (cc + 1) / 2)
+        if ((wfl + (size_t)cc * p.CHP + 64) * 4 <= budget) { p.cc = cc; break; }
     p.lds_floats = (int)(wfl + (size_t)p.cc * p.CHP + 64);
     p.odb = (d->OD + p.TD - 1) / p.TD; p.ohb = (d->OH + p.TH - 1) / p.TH;
     p.items = d->N * p.odb * p.ohb;
@@ -243,7 +262,20 @@ int vg_corr3d_s1_mfma(const vg_conv_desc* d, const float* x, const float* wpk, c
     // (convt3 141 vs 182 us), because there the per-tile staging (halo re-reads, two barriers per 4 channels) dominates
     const double gflop = 2.0 * 27.0 * d->CI * d->CO * (double)d->N * d->OD * d->OH * d->OW * 1e-9;
     if (gflop > 2.0) return -1;
-    if (d->CO == 8) return launch_s1m<true, 4>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s);
-    if (d->CO == 16) return launch_s1m<false, 4>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s);
+    // accumulator tiles per wave: the smallest instance whose 4*NG groups still hold the tile the planner would pick
+    // (a tiny layer on a 4-tile instance issues 4 matrix instructions per k-step for 1 useful one)
+    const int PRr = d->CO == 8 ? (d->OW + 1) / 2 : d->OW;
+    const long plane_groups = ((long)d->OH * PRr + 15) / 16;
+    const bool few = (long)d->N * d->OD < 256;                   // one plane per item is already more than enough work per item
+    if (d->CO == 8) {
+        if (few && plane_groups <= 4) return launch_s1m<true, 1>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s);
+        if (few && plane_groups <= 8) return launch_s1m<true, 2>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s);
+        return launch_s1m<true, 4>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s);
+    }
+    if (d->CO == 16) {
+        if (few && plane_groups <= 4) return launch_s1m<false, 1>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s);
+        if (few && plane_groups <= 8) return launch_s1m<false, 2>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s);
+        return launch_s1m<false, 4>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s);
+    }
     return -1;
 }
