@@ -733,6 +733,7 @@ struct WgradRowsParams {
     int b_off, bch;
     int lds_floats;
     int items;
+    int wave_slabs;             // small grids: every wave writes its own slab (no cross-wave LDS reduction: 4 serial rounds, ~13 us)
 };
 
 template <int CA, int TC, int KD, int KH, int KW, int S, bool PAD, bool PA, int UG, bool RES>
@@ -897,6 +898,18 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
             });
         }
     }
+    if (p.wave_slabs) {
+        float* out = ws + ((size_t)blockIdx.x * nwaves + wave) * CB * (CA * KVOL);
+        const int cb0 = (lane >> 4) * 4, tapl = lane & 15;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int ca = t / TC, tap = (t % TC) * 16 + tapl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (cb0 + r < CB && tap < KVOL) out[(size_t)(cb0 + r) * (CA * KVOL) + ca * KVOL + tap] = acc[t].v[r];
+        }
+        return;
+    }
     // ---- cross-wave reduction through LDS (one wave at a time), then one slab per block
     float* red = lds;
     __syncthreads();
@@ -959,6 +972,10 @@ int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const fl
             const double halo = (double)(td * S) * (th * S) / ((double)p.LD * p.AR);
             double score = util * pos / (pos + 96.0) * (0.6 + 0.4 * halo);
             if (p.nbuf == 1 && CA > 1) score *= 0.6;
+            // few-item layers (encoder end, 32 samples): one wave per SIMD runs its whole dependent chain exposed -- prefer
+            // tiles small enough that every CU gets a couple of blocks
+            const long items = (long)d->N * vg_cdiv(d->PD, td) * vg_cdiv(d->PH, th);
+            if (items < 512) score *= ((double)items / 512.0) * ((double)items / 512.0);
             if (score > best_score) { best_score = score; best = p; }
         }
     if (best_score < 0) return -1;
@@ -986,11 +1003,13 @@ int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const fl
       if (cap_blocks > 0 && per_cu > cap_blocks) per_cu = cap_blocks; }
     int grid = 256 * per_cu; if (grid > p.items) grid = p.items;
     const int len = d->CB * CA * KVOL;
-    if (ws_bytes_only) { *ws_bytes_only = (int64_t)grid * len * sizeof(float); return VG_OK; }
+    p.wave_slabs = grid <= 512 ? 1 : 0;
+    const int nslabs = p.wave_slabs ? grid * 4 : grid;
+    if (ws_bytes_only) { *ws_bytes_only = (int64_t)nslabs * len * sizeof(float); return VG_OK; }
     vg_launch(kern, dim3(grid), dim3(256), fl * sizeof(float), s, a, b, in_scale, in_shift, ws, p);
     int rc = vg_check_launch("wgrad_rows");
     if (rc) return rc;
-    vg_launch(slab_sum_k, dim3(vg_cdiv(len, 64)), dim3(64 * SLAB_ROWS), 0, s, (const float*)ws, grid, len, accumulate, dw);
+    vg_launch(slab_sum_k, dim3(vg_cdiv(len, 64)), dim3(64 * SLAB_ROWS), 0, s, (const float*)ws, nslabs, len, accumulate, dw);
     return vg_check_launch("wgrad slab_sum");
 }
 
