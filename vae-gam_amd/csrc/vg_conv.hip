@@ -506,10 +506,18 @@ corr3d_mfma_k(const float* __restrict__ x, const float* __restrict__ wpk, const 
 
     // (no LDS clear: every read of a never-written word is discarded by a select, never multiplied)
     // ---- weight image wl[ci][ks][kk][co16] from the packed [ci][tap][co] weights (zero for tap >= KVOL, co >= CO)
-    for (int i = tid; i < CI * KS * 64; i += blockDim.x) {
-        const int co = i & 15, k4 = (i >> 4) & 3, r = i >> 6;
-        const int ks = r % KS, ci = r / KS, tap = 4 * ks + k4;
-        wl[i] = (tap < KVOL && co < CO) ? wpk[((size_t)ci * KVOL + tap) * CO + co] : 0.f;
+    //      (gathers in batches of 8 ahead of their LDS writes: a load -> wait -> write per iteration pays the memory latency 28 times)
+    for (int i0 = tid; i0 < CI * KS * 64; i0 += 8 * 256) {
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            const int co = i & 15, k4 = (i >> 4) & 3, r = i >> 6;
+            const int ks = r % KS, ci = r / KS, tap = 4 * ks + k4;
+            wv[u] = (i < CI * KS * 64 && tap < KVOL && co < CO) ? wpk[((size_t)ci * KVOL + tap) * CO + co] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (i0 + u * 256 < CI * KS * 64) wl[i0 + u * 256] = wv[u];
     }
     // ---- per-lane tap geometry of k-step ks (tap = 4 ks + kk)
     int tapOff[KS], tkd[KS], tkh[KS], tkw[KS];
