@@ -97,7 +97,7 @@ int vg_bn_finalize(const double* sums, int32_t G, int32_t C, const float* gamma,
                    float eps, float* scale, float* shift, float* mean, float* rstd, void* stream);
 /* vg_bn_stats from per-block partials another kernel produced (vg_tconv3d_s2_stats): fold + finalize.
  * count = elements per (group, channel); ext_sums != NULL: write the raw [sum, sumsq, count] triples there and stop
- * (data-parallel caller all-reduces, then vg_bn_finalize); else sums_ws (double[G*C*3]) is scratch. */
+ * (data-parallel caller all-reduces, then vg_bn_finalize); sums_ws is unused (kept for ABI stability, may be NULL). */
 int vg_bn_stats_from_parts(const double* part, int32_t G, int32_t C, int64_t chunks, double count,
                            const float* gamma, const float* beta, float eps, double* ext_sums, double* sums_ws,
                            float* scale, float* shift, float* mean, float* rstd, void* stream);

@@ -102,6 +102,27 @@ __global__ void bn_finalize_k(const double* __restrict__ sums, int G, int C, con
     scale[i] = sc; shift[i] = bt - (float)mu * sc; mean[i] = (float)mu; rstd[i] = rs;
 }
 
+// fold + finalize in one launch (single-GPU path: nothing to all-reduce between them): one wavefront per (group, channel)
+__global__ void __launch_bounds__(64)
+bn_fold_finalize_k(const double* __restrict__ part, int C, int chunks, double count, const float* __restrict__ gamma,
+                   const float* __restrict__ beta, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                   float* __restrict__ mean, float* __restrict__ rstd) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    double a = 0, b = 0;
+    for (int k = lane; k < chunks; k += VG_WAVE) { a += part[((size_t)i * chunks + k) * 2]; b += part[((size_t)i * chunks + k) * 2 + 1]; }
+    a = wave_sum(a); b = wave_sum(b);
+    if (lane == 0) {
+        const int c = i % C;
+        const double mu = a / count;
+        double var = b / count - mu * mu;                       // biased variance, as F.batch_norm
+        if (var < 0) var = 0;
+        const float rs = (float)(1.0 / sqrt(var + (double)eps));
+        const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+        const float sc = gm * rs;
+        scale[i] = sc; shift[i] = bt - (float)mu * sc; mean[i] = (float)mu; rstd[i] = rs;
+    }
+}
+
 // grid (chunks, C, G): dp = relu'(p) * gamma*rstd * (dxe - m1 - hhat*m2), in place over dxe
 __global__ void __launch_bounds__(BN_THREADS)
 bn_bwd_apply_k(float* __restrict__ dxe, const float* __restrict__ p, int C, long long P, int per_group, int relu,
@@ -207,10 +228,14 @@ extern "C" int vg_bn_stats(const float* x, int32_t N, int32_t C, int64_t P, int3
     vg_launch(bn_partial_k<0>, dim3(chunks, C, G), dim3(BN_THREADS), 0, s, x, (const float*)nullptr, (const float*)nullptr,
               (const float*)nullptr, (int)C, (long long)P, (int)per_group, (int)relu, pl.cp, part);
     if ((rc = vg_check_launch("bn_partial"))) return rc;
+    if (!ext_sums) {
+        if (!scale || !shift || !mean || !rstd) { vg_set_error("vg_bn_stats: null output"); return VG_ERR_ARG; }
+        vg_launch(bn_fold_finalize_k, dim3(G * C), dim3(64), 0, s, (const double*)part, (int)C, chunks, (double)total, gamma, beta, eps,
+                  scale, shift, mean, rstd);
+        return vg_check_launch("bn_fold_finalize");
+    }
     vg_launch(bn_fold_k, dim3(G * C), dim3(64), 0, s, (const double*)part, G * C, chunks, (double)total, 3, sums);
-    if ((rc = vg_check_launch("bn_fold"))) return rc;
-    if (ext_sums) return VG_OK;                       // caller all-reduces, then calls vg_bn_finalize
-    return vg_bn_finalize(sums, G, C, gamma, beta, eps, scale, shift, mean, rstd, stream);
+    return vg_check_launch("bn_fold");                // caller all-reduces, then calls vg_bn_finalize
 }
 
 extern "C" int vg_bn_bwd_reduce(const float* dxe, const float* p, int32_t N, int32_t C, int64_t P, int32_t per_group,
@@ -283,13 +308,15 @@ extern "C" int vg_channel_sum(const float* x, int32_t N, int32_t C, int64_t P, v
 extern "C" int vg_bn_stats_from_parts(const double* part, int32_t G, int32_t C, int64_t chunks, double count,
                                       const float* gamma, const float* beta, float eps, double* ext_sums, double* sums_ws,
                                       float* scale, float* shift, float* mean, float* rstd, void* stream) {
-    if (!part || G <= 0 || C <= 0 || chunks <= 0 || !(count > 0) || (!ext_sums && !sums_ws)) { vg_set_error("vg_bn_stats_from_parts: bad argument"); return VG_ERR_ARG; }
+    if (!part || G <= 0 || C <= 0 || chunks <= 0 || !(count > 0)) { vg_set_error("vg_bn_stats_from_parts: bad argument"); return VG_ERR_ARG; }
     hipStream_t s = (hipStream_t)stream;
-    double* sums = ext_sums ? ext_sums : sums_ws;
-    vg_launch(bn_fold_k, dim3(G * C), dim3(64), 0, s, part, G * C, (int)chunks, count, 3, sums);
-    int rc = vg_check_launch("bn_fold(parts)");
-    if (rc || ext_sums) return rc;
-    return vg_bn_finalize(sums, G, C, gamma, beta, eps, scale, shift, mean, rstd, stream);
+    if (!ext_sums) {
+        if (!scale || !shift || !mean || !rstd) { vg_set_error("vg_bn_stats_from_parts: null output"); return VG_ERR_ARG; }
+        vg_launch(bn_fold_finalize_k, dim3(G * C), dim3(64), 0, s, part, (int)C, (int)chunks, count, gamma, beta, eps, scale, shift, mean, rstd);
+        return vg_check_launch("bn_fold_finalize(parts)");
+    }
+    vg_launch(bn_fold_k, dim3(G * C), dim3(64), 0, s, part, G * C, (int)chunks, count, 3, ext_sums);
+    return vg_check_launch("bn_fold(parts)");
 }
 
 namespace {

@@ -18,7 +18,8 @@ __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 
-// one block; wave per row
+// wave per row, 4 rows per block; every block scans all of `a` for the batch-wide floor flag itself (B*L is ~1 K numbers:
+// cheaper than a second launch or a grid-wide handshake)
 __global__ void __launch_bounds__(256)
 latent_fwd_k(const float* __restrict__ mu, const float* __restrict__ w, const float* __restrict__ a,
              const float* __restrict__ eps_w, const float* __restrict__ eps_d, int B, int L, int G,
@@ -32,9 +33,9 @@ latent_fwd_k(const float* __restrict__ mu, const float* __restrict__ w, const fl
     if (f) s_flag = 1;                                   // benign race: every writer stores 1
     __syncthreads();
     const float floor_ = s_flag ? 1e-6f : 0.f;
-    if (tid == 0) flag_out[0] = floor_;
+    if (tid == 0 && blockIdx.x == 0) flag_out[0] = floor_;
     const int Z = L + G;
-    for (int b = wave; b < B; b += nw) {
+    for (int b = blockIdx.x * nw + wave; b < B; b += gridDim.x * nw) {
         float s_wd = 0.f, s_ld = 0.f, s_d = 0.f, s_w = 0.f, s_m = 0.f;
         const float ew = eps_w[b];
         for (int l = lane; l < L; l += VG_WAVE) {
@@ -63,7 +64,7 @@ latent_bwd_k(const float* __restrict__ mu, const float* __restrict__ w, const fl
     const int lane = threadIdx.x % VG_WAVE, wave = vg_wave_id(), nw = blockDim.x / VG_WAVE;
     const int Z = L + G;
     const float floor_ = flag[0];
-    for (int b = wave; b < B; b += nw) {
+    for (int b = blockIdx.x * nw + wave; b < B; b += gridDim.x * nw) {
         float s_wd = 0.f;
         for (int l = lane; l < L; l += VG_WAVE) { const int i = b * L + l; s_wd += w[i] * w[i] / d_in[i]; }
         const float cap = 1.f + wsum(s_wd);
@@ -116,7 +117,7 @@ extern "C" int vg_latent_fwd(const float* mu, const float* w, const float* a, co
                              void* stream) {
     if (!mu || !w || !a || !eps_w || !eps_d || !zcat || !kl || !d_out || !flag_out) { vg_set_error("vg_latent_fwd: null argument"); return VG_ERR_ARG; }
     if (B <= 0 || L <= 0 || G <= 0 || (int64_t)B * L > (1 << 24)) { vg_set_error("vg_latent_fwd: bad shape"); return VG_ERR_ARG; }
-    vg_launch(latent_fwd_k, dim3(1), dim3(256), 0, (hipStream_t)stream, mu, w, a, eps_w, eps_d, (int)B, (int)L, (int)G, zcat, kl,
+    vg_launch(latent_fwd_k, dim3((B + 3) / 4 < 64 ? (B + 3) / 4 : 64), dim3(256), 0, (hipStream_t)stream, mu, w, a, eps_w, eps_d, (int)B, (int)L, (int)G, zcat, kl,
               d_out, flag_out);
     return vg_check_launch("latent_fwd");
 }
@@ -126,7 +127,7 @@ extern "C" int vg_latent_bwd(const float* mu, const float* w, const float* d, co
                              float* g_mu, float* g_w, float* g_a, void* stream) {
     if (!mu || !w || !d || !flag || !eps_w || !eps_d || !g_mu || !g_w || !g_a) { vg_set_error("vg_latent_bwd: null argument"); return VG_ERR_ARG; }
     if (B <= 0 || L <= 0 || G <= 0 || (int64_t)B * L > (1 << 24)) { vg_set_error("vg_latent_bwd: bad shape"); return VG_ERR_ARG; }
-    vg_launch(latent_bwd_k, dim3(1), dim3(256), 0, (hipStream_t)stream, mu, w, d, flag, eps_w, eps_d, g_zcat, g_kl, (int)B, (int)L,
+    vg_launch(latent_bwd_k, dim3((B + 3) / 4 < 64 ? (B + 3) / 4 : 64), dim3(256), 0, (hipStream_t)stream, mu, w, d, flag, eps_w, eps_d, g_zcat, g_kl, (int)B, (int)L,
               (int)G, g_mu, g_w, g_a);
     return vg_check_launch("latent_bwd");
 }

@@ -946,7 +946,10 @@ int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const fl
     const bool narrow = d->PW < 12;                 // 5..7-position rows: only worth it with every channel resident (rows outermost)
     if (!PAD && ((d->PD - 1) * S + KD > d->AD || (d->PH - 1) * S + KH > d->AH || (d->PW - 1) * S + KW > d->AW)) return -1;
     static const long cap_env = getenv("VG_WGRAD_LDS") ? atol(getenv("VG_WGRAD_LDS")) : 0;
-    const size_t cap = cap_env > 0 ? (size_t)cap_env : (size_t)(narrow ? 48 : NT >= 16 ? 40 : 24) * 1024;
+    // LDS per block: measured sweep (tools/layer_bench.py, VG_WGRAD_LDS): 56 KB is best or equal for every layer of the net
+    // (convt4 212 -> 187 us, convt2 104 -> 92, convt5 130 -> 119 vs 24-48 KB); 64 KB leaves one block per CU too few
+    const size_t cap = cap_env > 0 ? (size_t)cap_env : (size_t)56 * 1024;
+    (void)narrow;
     const size_t red_fl = (size_t)NT * 4 * VG_WAVE;
     const int front = 4;                            // >= pad_w: the first window of a padded row starts before the slot's row
     WgradRowsParams best; double best_score = -1;
