@@ -623,6 +623,40 @@ class LinearAct(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+class HeadsAct(torch.autograd.Function):
+    """The three encoder heads (vae_reg_GP.py:205-209, 246-252: fc31/32/33 -> ReLU -> fc41/42/43) as ONE GEMM over the stacked
+    first-stage weights and ONE batched GEMM over the second stage.  W3 [3*H, F], b3 [3*H], W4 [3, L, H], b4 [3, 1, L] are
+    views of the flat parameter buffer (the optimiser lays the six weights / six biases out back to back), gW3.. the matching
+    views of the flat gradient buffer, which the backward adds into directly.  9 -> 3 launches forward, 23 -> 8 backward."""
+
+    @staticmethod
+    def forward(ctx, h, W3, b3, W4, b4, gW3, gb3, gW4, gb4):
+        B = h.shape[0]
+        y = torch.relu_(torch.addmm(b3, h, W3.t()))                      # (B, 3H)
+        X = y.view(B, 3, -1).transpose(0, 1)                             # (3, B, H), strided view
+        out = torch.baddbmm(b4, X, W4.transpose(1, 2))                   # (3, B, L)
+        ctx.save_for_backward(h, y, W3, W4)
+        ctx.grads = (gW3, gb3, gW4, gb4)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        h, y, W3, W4 = ctx.saved_tensors
+        gW3, gb3, gW4, gb4 = ctx.grads
+        B = h.shape[0]
+        gout = gout.contiguous()
+        X = y.view(B, 3, -1).transpose(0, 1)
+        gX = torch.bmm(gout, W4)                                         # (3, B, H)
+        gW4.baddbmm_(gout.transpose(1, 2), X)                            # += gout^T X
+        ones = _ones(B, gout.device)
+        gb4.baddbmm_(ones.view(1, 1, B).expand(3, 1, B), gout)           # += column sums
+        gy = torch.ops.aten.threshold_backward(gX.transpose(0, 1).reshape(B, -1), y, 0.0)
+        gh = gy @ W3
+        gW3.addmm_(gy.t(), h)
+        gb3.addmv_(gy.t(), ones)
+        return gh, None, None, None, None, None, None, None, None
+
+
 _ONES = {}
 
 

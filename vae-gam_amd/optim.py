@@ -17,7 +17,11 @@ from . import ops
 
 
 class FusedAdam:
-    def __init__(self, named_params: Sequence[Tuple[str, torch.nn.Parameter]], lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, named_params: Sequence[Tuple[str, torch.nn.Parameter]], lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 contiguous_groups: Sequence[Sequence[str]] = ()):
+        """contiguous_groups: lists of parameter names laid out back to back (no padding between them) so that the model can
+        view them as ONE stacked weight (the three encoder heads run as one GEMM / one batched GEMM).  The order inside
+        the flat buffer is private: state_dict() indexes by position in `named_params`."""
         self.names = [n for n, _ in named_params]
         self.params: List[torch.nn.Parameter] = [p for _, p in named_params]
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
@@ -30,11 +34,28 @@ class FusedAdam:
             idx = [i for i, p in enumerate(self.params) if p.dtype == dtype]
             if not idx:
                 continue
+            by_name = {self.names[i]: i for i in idx}
+            packed, spans = [], {}
+            for grp in contiguous_groups:
+                if all(n in by_name for n in grp):
+                    packed.append([by_name[n] for n in grp])
+            in_pack = {i for g_ in packed for i in g_}
+            order = [i for g_ in packed for i in g_] + [i for i in idx if i not in in_pack]
+            last_of_group = {g_[-1] for g_ in packed}
+            idx = order
             sizes = [self.params[i].numel() for i in idx]
             offs = [0]
-            for s in sizes:
-                offs.append(offs[-1] + ((s + 3) // 4) * 4)           # keep every view 16-byte aligned
+            for i, s in zip(idx, sizes):
+                nxt = offs[-1] + s
+                if i not in in_pack or i in last_of_group:
+                    nxt = ((nxt + 3) // 4) * 4                       # keep every free-standing view 16-byte aligned
+                offs.append(nxt)
             total = offs[-1]
+            for g_ in packed:
+                k0 = idx.index(g_[0])
+                spans[tuple(self.names[i] for i in g_)] = (offs[k0], sum(self.params[i].numel() for i in g_))
+            self._spans = getattr(self, '_spans', {})
+            self._spans.update({k: (dtype,) + v for k, v in spans.items()})
             flat_p = torch.zeros(total, dtype=dtype, device=device)
             flat_g = torch.zeros(total, dtype=dtype, device=device)
             for k, i in enumerate(idx):
@@ -49,6 +70,15 @@ class FusedAdam:
         self._scalars_host = torch.zeros(2, dtype=torch.float64)
         if device.type == 'cuda':
             self._scalars_host = self._scalars_host.pin_memory()
+
+    def group_views(self, names):
+        """(parameters, gradients) of a contiguous group as flat 1-D views of the flat buffers, or None."""
+        sp = getattr(self, '_spans', {}).get(tuple(names))
+        if sp is None:
+            return None
+        dtype, off, n = sp
+        gr = self.groups[dtype]
+        return gr['p'][off:off + n], gr['g'][off:off + n]
 
     # ---- torch.optim-like surface
     @property

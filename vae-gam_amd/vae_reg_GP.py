@@ -112,7 +112,15 @@ class VAE(nn.Module):
         self._build_network()
         self.to(self.device)
         named = list(self.named_parameters())
-        self.optimizer = FusedAdam(named, lr=self.lr)
+        head_groups = [['fc31.weight', 'fc32.weight', 'fc33.weight'], ['fc31.bias', 'fc32.bias', 'fc33.bias'],
+                       ['fc41.weight', 'fc42.weight', 'fc43.weight'], ['fc41.bias', 'fc42.bias', 'fc43.bias']]
+        self.optimizer = FusedAdam(named, lr=self.lr, contiguous_groups=head_groups)
+        self._heads = None
+        hv = [self.optimizer.group_views(g_) for g_ in head_groups]
+        if all(v is not None for v in hv):
+            H, F_, L_ = self.fc31.out_features, self.fc31.in_features, self.fc41.out_features
+            shapes = [(3 * H, F_), (3 * H,), (3, L_, H), (3, 1, L_)]
+            self._heads = tuple(v[0].view(sh) for v, sh in zip(hv, shapes)) + tuple(v[1].view(sh) for v, sh in zip(hv, shapes))
         # parameters that take part in training (the reference's Adam only ever creates state for those):
         # everything except the gain sets of covariates beyond num_covariates
         used_gain = {c.name for c in self.schema}
@@ -229,6 +237,9 @@ class VAE(nn.Module):
         h = F.relu(p).reshape(p.shape[0], -1)
         h = la(self.fc1, h, True)
         h = la(self.fc2, h, True)
+        if self._heads is not None and self._heads[0].device == h.device:
+            out = ops.HeadsAct.apply(h, *self._heads)                    # the three heads: one GEMM + one batched GEMM
+            return out[0], out[1], out[2]
         mu = la(self.fc41, la(self.fc31, h, True), False)
         w = la(self.fc42, la(self.fc32, h, True), False)
         a = la(self.fc43, la(self.fc33, h, True), False)
