@@ -60,7 +60,7 @@ def alg_bytes_per_launch(key, model, B):
     else:
         return None
     n_in = N * sp.ci * int(np.prod(sizes[i])); n_out = N * sp.co * int(np.prod(sizes[i + 1]))
-    if fn in ('vg_corr3d', 'vg_tconv3d_s2'):
+    if fn in ('vg_corr3d', 'vg_tconv3d_s2', 'vg_tconv3d_s2_stats'):
         extra = n_in if (direction == 'bwd') else 0          # bwd: + the saved activation read for the fused ReLU mask
         return 4 * (n_in + n_out + extra)
     if fn == 'vg_wgrad3d':
