@@ -564,6 +564,38 @@ class LatentSample(torch.autograd.Function):
         return g_mu, g_w, g_a, None, None, None
 
 
+class LatentSampleStacked(torch.autograd.Function):
+    """LatentSample on the stacked heads output mwa[3, B, L] = (mu, w, a): one gradient tensor goes back to HeadsAct
+    (indexing mwa[0..2] under autograd costs three select-backward fills + copies + two adds per step)."""
+
+    @staticmethod
+    def forward(ctx, mwa, eps_w, eps_d, G):
+        mwa = _chk(mwa.contiguous())
+        _, B, L = mwa.shape
+        eps_w = _chk(eps_w.contiguous()); eps_d = _chk(eps_d.contiguous())
+        assert eps_d.shape == (B, L) and eps_w.numel() == B
+        zcat = torch.empty((G * B, L + G), dtype=torch.float32, device=mwa.device)
+        kl = torch.empty(B, dtype=torch.float32, device=mwa.device)
+        d = torch.empty((B, L), dtype=torch.float32, device=mwa.device)
+        flag = torch.empty(1, dtype=torch.float32, device=mwa.device)
+        _call(mwa, 'vg_latent_fwd', _p(mwa[0]), _p(mwa[1]), _p(mwa[2]), _p(eps_w), _p(eps_d), B, L, G, _p(zcat), _p(kl), _p(d), _p(flag))
+        ctx.save_for_backward(mwa, d, flag, eps_w, eps_d)
+        ctx.G = G
+        ctx.mark_non_differentiable(d)
+        return zcat, kl, d
+
+    @staticmethod
+    def backward(ctx, g_zcat, g_kl, _g_d):
+        mwa, d, flag, eps_w, eps_d = ctx.saved_tensors
+        _, B, L = mwa.shape
+        g = torch.empty_like(mwa)
+        gz = _p(_chk(g_zcat.contiguous())) if g_zcat is not None else None
+        gk = _p(_chk(g_kl.contiguous())) if g_kl is not None else None
+        _call(mwa, 'vg_latent_bwd', _p(mwa[0]), _p(mwa[1]), _p(d), _p(flag), _p(eps_w), _p(eps_d), gz, gk, B, L, ctx.G,
+                 _p(g[0]), _p(g[1]), _p(g[2]))
+        return g, None, None, None
+
+
 class ElboLoss(torch.autograd.Function):
     """loss[1] = c_kl*sum(kl_z) + c_slp*sum(slp) + c_gp*gp_kl + c_dist*sum(dist)   (vae_reg_GP.py:406-410)."""
 

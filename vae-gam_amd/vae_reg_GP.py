@@ -230,7 +230,7 @@ class VAE(nn.Module):
         self._packed.refresh()
         return self._encode(x)
 
-    def _encode_heads(self, x):
+    def _encode_heads(self, x, stacked=False):
         """-> mu (B,L), w (B,L), a (B,L) with u = w[..., None], d = exp(a)."""
         p = self._encode_pre(x)
         la = ops.linear_act
@@ -239,7 +239,7 @@ class VAE(nn.Module):
         h = la(self.fc2, h, True)
         if self._heads is not None and self._heads[0].device == h.device:
             out = ops.HeadsAct.apply(h, *self._heads)                    # the three heads: one GEMM + one batched GEMM
-            return out[0], out[1], out[2]
+            return out if stacked else (out[0], out[1], out[2])
         mu = la(self.fc41, la(self.fc31, h, True), False)
         w = la(self.fc42, la(self.fc32, h, True), False)
         a = la(self.fc43, la(self.fc33, h, True), False)
@@ -408,11 +408,16 @@ class VAE(nn.Module):
                 gains = self._gains(covariates, noise['eps_beta'])
         else:
             gains = self._gains(covariates, noise['eps_beta'])
-        mu, w, a = self._encode_heads(x)
+        heads = self._encode_heads(x, stacked=True)
         G = C + 1
         # d = exp(a) + 1e-6*[any(d < 1e-6)] (:321-323, no sync), z = rsample (:325), kl_z (:400) and the G decoder
         # inputs [z, onehot] (:326-329, 339-342) in ONE launch (and one for the backward)
-        zcat, kl_z, d = ops.LatentSample.apply(mu, w, a, eps_w, eps_d, G)
+        if torch.is_tensor(heads):                                       # stacked (3, B, L): one tensor in, one gradient back
+            zcat, kl_z, d = ops.LatentSampleStacked.apply(heads, eps_w, eps_d, G)
+            mu, w = heads[0], heads[1]
+        else:
+            mu, w, a = heads
+            zcat, kl_z, d = ops.LatentSample.apply(mu, w, a, eps_w, eps_d, G)
         z, u = zcat[:B, :L], w.unsqueeze(-1)
         logits = self._decode_logits(zcat, B).view(G, B, self.img_dim)
         task_var, gp_kl_loss, beta_mean, beta_cov, post = gains
