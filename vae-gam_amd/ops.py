@@ -618,6 +618,9 @@ class ElboLoss(torch.autograd.Function):
         return g_kl, g_slp, g_dist, g_gp, None
 
 
+_FUSED_RELU_GEMM = hasattr(torch, '_addmm_activation') and bool(int(_os.environ.get('VG_FUSED_RELU_GEMM', '1')))
+
+
 class LinearAct(torch.autograd.Function):
     """y = [relu](x @ W^T + b) for the fully connected layers (vae_reg_GP.py:203-209, 224-234): the GEMMs stay in
     hipBLASLt (plain library GEMMs), but the backward adds dW / db straight into the .grad views of the flat gradient
@@ -625,9 +628,12 @@ class LinearAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
-        y = torch.addmm(bias, x, weight.t())
-        if relu:
-            y = torch.relu_(y)
+        if relu and _FUSED_RELU_GEMM:
+            y = torch._addmm_activation(bias, x, weight.t())             # bias + ReLU in the GEMM epilogue (one launch)
+        else:
+            y = torch.addmm(bias, x, weight.t())
+            if relu:
+                y = torch.relu_(y)
         ctx.relu = relu
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.bias_ref = bias
@@ -664,7 +670,7 @@ class HeadsAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, W3, b3, W4, b4, gW3, gb3, gW4, gb4):
         B = h.shape[0]
-        y = torch.relu_(torch.addmm(b3, h, W3.t()))                      # (B, 3H)
+        y = torch._addmm_activation(b3, h, W3.t()) if _FUSED_RELU_GEMM else torch.relu_(torch.addmm(b3, h, W3.t()))   # (B, 3H)
         X = y.view(B, 3, -1).transpose(0, 1)                             # (3, B, H), strided view
         out = torch.baddbmm(b4, X, W4.transpose(1, 2))                   # (3, B, L)
         ctx.save_for_backward(h, y, W3, W4)
