@@ -150,3 +150,63 @@ def test_synthetic_set_is_seeded_and_has_the_control_signal():
     on = a['volumes'][task == 1].mean(0); off = a['volumes'][task == 0].mean(0)
     assert (on - off)[sig > 0].mean() > 0.2                      # the glyph is there when the block is ON
     assert a['covariates'][:, 1].min() < -3 and a['covariates'][:, 1].max() > 3   # wide range keeps Ku conditioned (H2)
+
+
+def test_nifti1_writer_round_trip_and_reference_geometry(tmp_path):
+    import struct
+    from vae_gam_amd import nifti
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((5, 7, 3)).astype(np.float32)
+    p = str(tmp_path / 'm.nii')
+    nifti.write_nifti1(p, a)
+    np.testing.assert_array_equal(DataClass_GP.read_nifti1(p), a)
+    pz = str(tmp_path / 'm.nii.gz')
+    nifti.write_nifti1(pz, a.astype(np.float64))
+    np.testing.assert_array_equal(DataClass_GP.read_nifti1(pz), a)
+    # geometry of a reference file (pixdim, sform) survives; its int16 datatype / scaling do not leak into the float map
+    ref = bytearray(352)
+    struct.pack_into('<i', ref, 0, 348)
+    struct.pack_into('<8h', ref, 40, 3, 5, 7, 3, 1, 1, 1, 1)
+    struct.pack_into('<2h', ref, 70, 4, 16)
+    struct.pack_into('<8f', ref, 76, 1.0, 3.0, 3.0, 3.5, 1.4, 1.0, 1.0, 1.0)
+    struct.pack_into('<f', ref, 108, 352.0)
+    struct.pack_into('<2f', ref, 112, 2.0, 1.0)
+    struct.pack_into('<h', ref, 254, 2)
+    struct.pack_into('<4f', ref, 280, -3.0, 0.0, 0.0, 90.0)
+    refp = str(tmp_path / 'ref.nii')
+    open(refp, 'wb').write(bytes(ref) + np.zeros(5 * 7 * 3, np.int16).tobytes())
+    p2 = str(tmp_path / 'withref.nii')
+    nifti.write_nifti1(p2, a, reference=refp)
+    np.testing.assert_array_equal(DataClass_GP.read_nifti1(p2), a)
+    raw, en = nifti.read_header(p2)
+    assert struct.unpack(en + '8f', raw[76:108])[1:4] == (3.0, 3.0, 3.5)
+    assert struct.unpack(en + '4f', raw[280:296]) == (-3.0, 0.0, 0.0, 90.0)
+    assert struct.unpack(en + '2h', raw[70:74]) == (16, 32)
+
+
+def test_mk_avg_maps_from_device_sums(tmp_path):
+    """Subject means and the grand mean (mean of subject means, build_model_recons.py:86-99) from the sums reconstruct() leaves."""
+    import pandas as pd
+    from vae_gam_amd import build_model_recons as R
+
+    class FakeModel:
+        epoch = 7
+        img_shape = (3, 4, 2)
+    V = 24
+    rng = np.random.default_rng(1)
+    per_vol = {0: rng.standard_normal((5, V)), 1: rng.standard_normal((3, V))}            # subject -> (volumes, V)
+    m = FakeModel()
+    sums = {'base': torch.tensor(np.stack([per_vol[0].sum(0), per_vol[1].sum(0)])),
+            'x_mot': torch.zeros(2, V, dtype=torch.float64), 'full_rec': torch.ones(2, V, dtype=torch.float64)}
+    m.recon_sums = (sums, torch.tensor([5.0, 3.0], dtype=torch.float64))
+    csv = str(tmp_path / 'd.csv')
+    pd.DataFrame({'i': range(8), 'subjid': ['sA'] * 5 + ['sB'] * 3, 'vol': list(range(5)) + list(range(3)),
+                  'nii_path': ['a.npy'] * 5 + ['b.npy'] * 3}).to_csv(csv, index=False)
+    out = R.mk_avg_maps(csv, m, str(tmp_path))
+    assert set(out) == {'base', 'full_rec'}                                               # motion maps only on request
+    want = 0.5 * (per_vol[0].mean(0) + per_vol[1].mean(0))
+    np.testing.assert_allclose(out['base'].reshape(-1), want, rtol=1e-6, atol=1e-6)
+    d = tmp_path / 'reconstructions' / '007_avg_model_recons'
+    np.testing.assert_allclose(DataClass_GP.read_nifti1(str(d / 'sB' / 'base_avg.nii')).reshape(-1), per_vol[1].mean(0), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(DataClass_GP.read_nifti1(str(d / 'base_avg.nii')).reshape(-1), want, rtol=1e-5, atol=1e-6)
+    assert 'x_mot' in R.mk_avg_maps(csv, m, str(tmp_path), mk_motion_maps=True)

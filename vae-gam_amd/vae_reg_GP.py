@@ -140,6 +140,7 @@ class VAE(nn.Module):
         self.overlap_gains = True      # run the gain algebra on a second stream beside the conv stacks
         self._glm_f32 = None
         self.use_hip_graph = False     # capture the train step into a hipGraph (bench / long runs)
+        self.recon_sums = None         # per-subject map sums left by reconstruct() for build_model_recons.mk_avg_maps
         self._graphs = {}
 
     # ------------------------------------------------------------------ construction helpers
@@ -641,6 +642,46 @@ class VAE(nn.Module):
         self.inducing_pts = checkpoint['inducing_pts']
 
     # ------------------------------------------------------------------ post-hoc (reconstruction export lives in build_model_recons)
+    def reconstruct(self, loader, ref_niis, save_dirs, write_volumes=True):
+        """Reference signature (vae_reg_GP.py:585-620): one `recon_<map>.nii` per volume and map under
+        save_dirs[subject]/vol_<n>/, written with the geometry of that subject's reference NIfTI.
+        The maps stay on the device until they are written; per-subject sums of every map are accumulated there as
+        well (`self.recon_sums`), so that build_model_recons.mk_avg_maps does not have to re-read the files.
+        write_volumes=False only accumulates."""
+        import os
+        from . import nifti
+        C = self.num_covariates
+        keys = ['base'] + [c.img_key for c in self.schema] + ['full_rec']
+        S = len(save_dirs)
+        sums = {k: torch.zeros(S, self.img_dim, device=self.device, dtype=torch.float64) for k in keys}
+        counts = torch.zeros(S, device=self.device, dtype=torch.float64)
+        refs = {}
+        with torch.no_grad():
+            for sample in loader:
+                ids, covariates, x = self._batch_to_device(sample)
+                out = self.forward_core(covariates, x, want_maps=True)
+                maps = out['maps']                                         # (C+2, B, V) on the device
+                idl = ids.long()
+                counts.index_add_(0, idl, torch.ones_like(idl, dtype=torch.float64))
+                for j, k in enumerate(keys):
+                    sums[k].index_add_(0, idl, maps[j].double())
+                if not write_volumes:
+                    continue
+                host = maps.cpu().numpy()
+                vol_num = [int(v) for v in sample['vol_num'].tolist()]
+                subjidx = [int(v) for v in sample['subjid'].tolist()]
+                for j, k in enumerate(keys):
+                    for b in range(host.shape[1]):
+                        si = subjidx[b]
+                        vol_dir = os.path.join(save_dirs[si], 'vol_{}'.format(vol_num[b]))
+                        os.makedirs(vol_dir, exist_ok=True)
+                        ref = ref_niis[si] if si < len(ref_niis) else None
+                        if ref not in refs:
+                            refs[ref] = ref if (ref is not None and str(ref).endswith(('.nii', '.nii.gz')) and os.path.exists(str(ref))) else None
+                        nifti.write_nifti1(os.path.join(vol_dir, 'recon_{}.nii'.format(k)), host[j, b].reshape(self.img_shape), refs[ref])
+        self.recon_sums = (sums, counts)
+        return sums, counts
+
     def reconstruct_batch(self, ids, covariates, x):
         """Maps of one batch as ndarrays keyed like the reference's `imgs` (vae_reg_GP.py:605)."""
         with torch.no_grad():
