@@ -210,3 +210,46 @@ def test_mk_avg_maps_from_device_sums(tmp_path):
     np.testing.assert_allclose(DataClass_GP.read_nifti1(str(d / 'sB' / 'base_avg.nii')).reshape(-1), per_vol[1].mean(0), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(DataClass_GP.read_nifti1(str(d / 'base_avg.nii')).reshape(-1), want, rtol=1e-5, atol=1e-6)
     assert 'x_mot' in R.mk_avg_maps(csv, m, str(tmp_path), mk_motion_maps=True)
+
+
+def test_gp_posterior_diagonal_equals_full_posterior_diagonal():
+    from vae_gam_amd import gp
+    g = torch.Generator().manual_seed(0)
+    K, n, N = 3, 6, 40
+    xu = torch.stack([torch.linspace(-4.0 - k, 6.0 + k, n) for k in range(K)]).double()
+    kvar = (torch.rand(K, generator=g) + 0.2).double(); ls = (torch.rand(K, generator=g) * 2 + 0.8).double()
+    qu_m = torch.randn(K, n, generator=g).double()
+    r = torch.randn(K, n, n, generator=g).double(); qu_S = r @ r.transpose(1, 2) + 0.5 * torch.eye(n).double()
+    xq = (torch.rand(K, N, generator=g) * 9 - 4).double()
+    f_full, S_full = gp.posterior_batched(xu, kvar, ls, qu_m, qu_S, xq)
+    f_d, v_d = gp.posterior_diag_batched(xu, kvar, ls, qu_m, qu_S, xq)
+    np.testing.assert_allclose(f_d.numpy(), f_full.numpy(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(v_d.numpy(), torch.diagonal(S_full, dim1=1, dim2=2).numpy(), rtol=1e-9, atol=1e-10)
+
+
+def test_plot_GPs_csv_export_matches_per_covariate_posterior(small_ds, tmp_path):
+    """SURVEY 8f-2 (vae_reg_GP.py:641-673): sorted xq / mean / vars per continuous covariate == the reference's
+    recipe evaluated with the full (N x N) posterior of gp.GP."""
+    import pandas as pd
+    from vae_gam_amd import gp
+    csv, _ = synthetic.write_csvs(small_ds, str(tmp_path))
+    torch.manual_seed(2)
+    m = VAE(num_covariates=8, glm_maps=small_ds['glm'], xu_ranges=small_ds['xu_ranges'], device_name='cpu', save_dir=str(tmp_path))
+    m.epoch = 4
+    out = m.plot_GPs(csv_file=csv, save_dir=str(tmp_path))
+    assert sorted(out) == sorted(['x', 'y', 'z', 'xrot', 'yrot', 'zrot'])
+    data = pd.read_csv(csv)
+    name, col = 'yrot', 'rot_y'
+    f = pd.read_csv(str(tmp_path / '004_GP_plots' / ('004_GP_%s_full.csv' % name)), index_col=0)
+    assert list(f.columns) == ['xq', 'mean', 'vars'] and np.all(np.diff(f['xq'].to_numpy()) >= 0)
+    P = m.gp_params[name]
+    xq = torch.from_numpy(data[col].to_numpy(dtype=np.float32)).double()
+    G = gp.GP(P['xu'].double(), P['logkvar'].double().exp() + 0.1, 3.0 * torch.sigmoid(P['log_ls'].double().exp() + 0.5),
+              P['qu_m'].double(), P['qu_S'].double())
+    with torch.no_grad():
+        f_bar, Sigma = G.evaluate_posterior(xq)
+        mean = P['sa'][0].double() * xq + f_bar
+        var = P['logstd'][0].double().exp() ** 2 * xq ** 2 + torch.diagonal(Sigma)
+    order = f.index.to_numpy()
+    np.testing.assert_allclose(f['mean'].to_numpy(), mean.numpy()[order], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(f['vars'].to_numpy(), var.numpy()[order], rtol=1e-6, atol=1e-8)

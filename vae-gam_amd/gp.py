@@ -53,6 +53,28 @@ def posterior_batched(xu, k_var, ls, qu_m, qu_S, xq):
     return f_bar, Sigma
 
 
+def posterior_diag_batched(xu, k_var, ls, qu_m, qu_S, xq):
+    """Posterior mean and VARIANCE (diagonal of Sigma only) of K independent 1-D GPs at N query points each:
+    f_bar (K,N), var (K,N) = k_var + rowsum((A M) * A), M = qu_S - k_var Ku1, in O(N n^2) time and O(N n) memory.
+    The full-data-set export (vae_reg_GP.py:641-673) asks the reference for the N x N covariance of ALL volumes and
+    keeps its diagonal; this is that diagonal without the N x N matrix (same A as posterior_batched)."""
+    K, n = xu.shape
+    step = (xu[:, 1] - xu[:, 0]).detach()
+    d0 = xu[:, 0].detach().double().unsqueeze(1) - xq.detach().double()
+    kidx = torch.arange(n, device=xu.device, dtype=torch.float64)
+    knu_d = (d0.unsqueeze(1) + kidx.view(1, n, 1) * step.double().view(K, 1, 1)).float().to(xq.dtype)
+    kv, l_ = k_var.view(K, 1, 1), ls.view(K, 1, 1)
+    one = torch.ones((), device=xu.device, dtype=xq.dtype)
+    step = step.to(xq.dtype)
+    knu1 = distance_to_kernel(knu_d, one, l_)
+    ku1 = distance_to_kernel(striped_matrix(n, xu.device, xq.dtype).unsqueeze(0) * step.view(K, 1, 1), one, l_)
+    ku1_inv = torch.linalg.inv_ex(ku1, check_errors=False).inverse
+    A = knu1.transpose(1, 2) @ ku1_inv                                                      # (K,N,n)
+    f_bar = (A @ qu_m.unsqueeze(-1)).squeeze(-1)
+    var = k_var.view(K, 1) + ((A @ (qu_S - kv * ku1)) * A).sum(-1)                          # k(0) = 1 for the unit kernel
+    return f_bar, var
+
+
 def kl_batched(qu_m, qu_S, prior_var=10.0):
     """KL(N(qu_m, qu_S) || N(0, prior_var*I)) for K GPs (gp.py:41-65), Cholesky of the unconstrained qu_S."""
     K, n = qu_m.shape

@@ -682,6 +682,49 @@ class VAE(nn.Module):
         self.recon_sums = (sums, counts)
         return sums, counts
 
+    def plot_GPs(self, csv_file='', save_dir=''):
+        """The CSV part of the reference's plot_GPs (vae_reg_GP.py:641-673): for every continuous covariate one
+        `<epoch>_GP_<name>_full.csv` with the data set's covariate values sorted ascending and the posterior gain mean
+        `sa*x + f_bar(x)` and variance `std^2 x^2 + diag(Sigma)(x)` at each of them (columns xq, mean, vars; the index column
+        holds the original row numbers, as pandas writes a sorted frame).  The reference builds the N x N posterior
+        covariance of all N volumes for its diagonal; gp.posterior_diag_batched gives the diagonal directly, in float64 like the
+        training path.  The matplotlib figures are not produced.  Returns {name: DataFrame}."""
+        import os
+        import pandas as pd
+        from .schema import REF_CSV_COLS
+        plot_dir = os.path.join(save_dir, str(self.epoch).zfill(3) + '_GP_plots')
+        os.makedirs(plot_dir, exist_ok=True)
+        data = pd.read_csv(csv_file)
+        gp_cov = [(i, c) for i, c in enumerate(self.schema) if c.gp]
+        out = {}
+        if not gp_cov:
+            return out
+        f64 = torch.float64
+        with torch.no_grad():
+            names = [c.name for _, c in gp_cov]
+            # covariate i (1-based position in the schema) reads data column REF_CSV_COLS[i-1] (:642-643, 658)
+            cols = []
+            for i, c in gp_cov:
+                col = REF_CSV_COLS[i - 1] if (i - 1) < len(REF_CSV_COLS) and REF_CSV_COLS[i - 1] in data.columns else c.name
+                cols.append(data[col].to_numpy(dtype=np.float32))
+            xq32 = torch.from_numpy(np.stack(cols)).to(self.device)                        # (K, N) fp32 as the data loader gives them
+            xq = xq32.to(f64)
+            xu = torch.stack([self.gp_params[n]['xu'] for n in names])
+            kvar = torch.stack([self.gp_params[n]['logkvar'] for n in names]).to(f64).exp() + 0.1
+            ls = 3.0 * torch.sigmoid(torch.stack([self.gp_params[n]['log_ls'] for n in names]).to(f64).exp() + 0.5)
+            qu_m = torch.cat([self.gp_params[n]['qu_m'] for n in names]).to(f64)
+            qu_S = torch.stack([self.gp_params[n]['qu_S'] for n in names]).to(f64)
+            f_bar, var = gp.posterior_diag_batched(xu, kvar, ls, qu_m, qu_S, xq)
+            sa = torch.cat([self.gp_params[n]['sa'][0] for n in names]).to(f64).unsqueeze(1)
+            std = torch.cat([self.gp_params[n]['logstd'][0] for n in names]).to(f64).exp().unsqueeze(1)
+            mean = (sa * xq + f_bar).cpu().numpy()
+            vars_ = (std.pow(2) * xq.pow(2) + var).cpu().numpy()
+        for k, n in enumerate(names):
+            df = pd.DataFrame({'xq': cols[k], 'mean': mean[k], 'vars': vars_[k]}).sort_values(by=['xq'])
+            df.to_csv(os.path.join(plot_dir, str(self.epoch).zfill(3) + '_GP_' + n + '_full.csv'))
+            out[n] = df
+        return out
+
     def reconstruct_batch(self, ids, covariates, x):
         """Maps of one batch as ndarrays keyed like the reference's `imgs` (vae_reg_GP.py:605)."""
         with torch.no_grad():
