@@ -253,3 +253,18 @@ def test_plot_GPs_csv_export_matches_per_covariate_posterior(small_ds, tmp_path)
     order = f.index.to_numpy()
     np.testing.assert_allclose(f['mean'].to_numpy(), mean.numpy()[order], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(f['vars'].to_numpy(), var.numpy()[order], rtol=1e-6, atol=1e-8)
+
+
+def test_glm_beta_maps_least_squares_and_scaling():
+    rng = np.random.default_rng(0)
+    T, R, V = 60, 7, 50
+    G = rng.standard_normal((T, R))
+    B = rng.standard_normal((R, V)) * 2 + 0.5
+    Y = (G @ B).T + 1e-9 * rng.standard_normal((V, T))
+    maps = utils.glm_beta_maps(G, Y, sex_map=np.linspace(0.1, 1.0, V))
+    assert maps.shape == (R + 1, V)
+    want = np.concatenate([B, np.linspace(0.1, 1.0, V)[None]], 0)
+    want = want / want.max(1, keepdims=True)                        # utils.scale_beta_maps: divide each map by its maximum
+    np.testing.assert_allclose(maps, want, rtol=1e-6, atol=1e-7)
+    with pytest.raises(ValueError):
+        utils.glm_beta_maps(G[:-1], Y)

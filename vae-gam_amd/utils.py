@@ -55,6 +55,23 @@ def scale_beta_maps(beta_maps):
     return beta_maps / beta_maps.max(1, keepdims=True)
 
 
+def glm_beta_maps(design, data, sex_map=None):
+    """Least-squares GLM maps used as the model's regulariser targets (get_beta_map_regularizer.py:94-107):
+    design (T, R) stacked design matrices (task + 6 motion columns), data (V, T) filtered voxel time courses
+    -> (R [+1], V) maps beta = (G^T G)^-1 G^T Y, the optional per-voxel `sex_map` appended as a last row, each row
+    divided by its maximum (scale_beta_maps).  The FSL .feat directory walk around it is preprocessing and not part
+    of this package; the `glm_maps` CSV the model reads is `pd.DataFrame(maps.T, columns=[...]).to_csv(...)`."""
+    G = np.asarray(design, dtype=np.float64)
+    Y = np.asarray(data, dtype=np.float64)
+    if Y.shape[1] != G.shape[0]:
+        raise ValueError('data has %d time points, design matrix %d rows' % (Y.shape[1], G.shape[0]))
+    pinv = np.linalg.inv(G.T @ G) @ G.T                       # (R, T), as the reference forms it (:95-96)
+    beta = pinv @ Y.T                                         # (R, V)
+    if sex_map is not None:
+        beta = np.concatenate([beta, np.asarray(sex_map, dtype=np.float64).reshape(1, -1)], axis=0)
+    return scale_beta_maps(beta)
+
+
 def log_map(writer, img_shape, maps, slice_idx, tag, batch_size, log_type):
     """Axial slice of every batch element to the writer (subset of utils.py:373-389; opt-in)."""
     add = getattr(writer, 'add_images', None)
