@@ -268,3 +268,21 @@ def test_glm_beta_maps_least_squares_and_scaling():
     np.testing.assert_allclose(maps, want, rtol=1e-6, atol=1e-7)
     with pytest.raises(ValueError):
         utils.glm_beta_maps(G[:-1], Y)
+
+
+def test_jsonl_scalar_log(small_ds, tmp_path):
+    """without tensorboard the per-epoch scalars land in <save_dir>/run/<date>/scalars.jsonl; no save_dir, no files."""
+    import json, glob
+    m = VAE(num_covariates=8, glm_maps=small_ds['glm'], xu_ranges=small_ds['xu_ranges'], device_name='cpu', save_dir=str(tmp_path))
+    m.writer.add_scalar('Loss/Train', torch.tensor(3.5), 2)
+    m._log_gain_scalars()
+    m.writer.close()
+    files = glob.glob(str(tmp_path / 'run' / '*' / 'scalars.jsonl'))
+    assert len(files) == 1
+    recs = [json.loads(l) for l in open(files[0])]
+    assert recs[0] == {'tag': 'Loss/Train', 'step': 2, 'value': 3.5}
+    tags = {r['tag'] for r in recs}
+    assert {'gain/task/sa', 'gp/x/k_var', 'gp/zrot/ls', 'epsilon/mean'} <= tags and 'gp/task/ls' not in tags
+    cwd_before = set(os.listdir('.'))
+    VAE(num_covariates=3, glm_maps=small_ds['glm'], xu_ranges=small_ds['xu_ranges'], device_name='cpu')
+    assert set(os.listdir('.')) == cwd_before

@@ -39,14 +39,48 @@ class _NullWriter:
         return lambda *a, **k: None
 
 
+class _JsonlWriter(_NullWriter):
+    """TensorBoard-free observability: the scalars the reference sends to its SummaryWriter
+    (utils.py:182-389, vae_reg_GP.py:703-704) as one JSON object per line in <log_dir>/scalars.jsonl, sampled per epoch.
+    add_scalar / add_scalars / flush / close are real; image and figure calls are accepted and dropped."""
+    def __init__(self, log_dir):
+        import json
+        self._json = json
+        os.makedirs(log_dir, exist_ok=True)
+        self.path = os.path.join(log_dir, 'scalars.jsonl')
+        self._f = open(self.path, 'a')
+
+    def add_scalar(self, tag, value, step=None, **_):
+        v = float(value.detach().cpu()) if torch.is_tensor(value) else float(value)
+        self._f.write(self._json.dumps({'tag': tag, 'step': None if step is None else int(step), 'value': v}) + '\n')
+
+    def add_scalars(self, main_tag, tag_scalar_dict, step=None, **_):
+        for k, v in tag_scalar_dict.items():
+            self.add_scalar('%s/%s' % (main_tag, k), v, step)
+
+    def flush(self):
+        self._f.flush()
+
+    def close(self):
+        self._f.flush(); self._f.close()
+        self._f = open(self.path, 'a')            # the reference keeps using the writer after train_loop closes it
+
+
 def _make_writer(log_dir, enabled):
-    if not enabled:
-        return _NullWriter()
-    try:
-        from torch.utils.tensorboard import SummaryWriter
-        return SummaryWriter(log_dir=log_dir)
-    except Exception:
-        return _NullWriter()
+    """tensorboard=True: the reference's SummaryWriter when the package is present; otherwise a JSONL scalar log
+    when there is a directory to write to, else a null writer."""
+    if enabled:
+        try:
+            from torch.utils.tensorboard import SummaryWriter
+            return SummaryWriter(log_dir=log_dir)
+        except Exception:
+            pass
+    if log_dir:
+        try:
+            return _JsonlWriter(log_dir)
+        except OSError:
+            pass
+    return _NullWriter()
 
 
 class VAE(nn.Module):
@@ -132,7 +166,8 @@ class VAE(nn.Module):
         self.epoch = 0
         self.loss = {'train': {}, 'test': {}}
         ts = datetime.datetime.now().date()
-        self.writer = _make_writer(os.path.join(self.save_dir, 'run', ts.strftime('%m_%d_%Y')), tensorboard)
+        # no save_dir: nothing is written anywhere (bench, tests); with one: <save_dir>/run/<date>/ as the reference (:181-184)
+        self.writer = _make_writer(os.path.join(self.save_dir, 'run', ts.strftime('%m_%d_%Y')) if self.save_dir else None, tensorboard)
         self.log_maps = False          # per-forward image logging of the reference; opt-in
         self._hrf_cache = {}
         self._gain_const_cache = {}
@@ -582,15 +617,31 @@ class VAE(nn.Module):
             loss = self.train_epoch(loaders['Shuffled_train'])
             self.loss['train'][epoch] = loss
             self.writer.add_scalar("Loss/Train", loss, self.epoch)
+            self._log_gain_scalars()
             self.writer.flush()
             if (test_freq is not None) and (epoch % test_freq == 0):
                 loss = self.test_epoch(loaders['test'])
                 self.loss['test'][epoch] = loss
+                self.writer.add_scalar("Loss/Test", loss, self.epoch)
             if (save_freq is not None) and (epoch % save_freq == 0) and (epoch > 0):
                 filename = "checkpoint_" + str(epoch).zfill(3) + '.tar'
                 file_path = os.path.join(save_dir, filename)
                 self.save_state(file_path)
         self.writer.close()
+
+    def _log_gain_scalars(self):
+        """Per-epoch gain / GP hyper-parameters (what utils.log_beta / log_qkappa_plots trace per forward in the reference)."""
+        if isinstance(self.writer, _NullWriter) and not isinstance(self.writer, _JsonlWriter):
+            return
+        with torch.no_grad():
+            for c in self.schema:
+                P = self.gp_params[c.name]
+                self.writer.add_scalar('gain/%s/sa' % c.name, P['sa'].reshape(-1)[0], self.epoch)
+                self.writer.add_scalar('gain/%s/std' % c.name, P['logstd'].reshape(-1)[0].exp(), self.epoch)
+                if c.gp:
+                    self.writer.add_scalar('gp/%s/k_var' % c.name, P['logkvar'].exp() + 0.1, self.epoch)
+                    self.writer.add_scalar('gp/%s/ls' % c.name, 3.0 * torch.sigmoid(P['log_ls'].exp() + 0.5), self.epoch)
+            self.writer.add_scalar('epsilon/mean', self.epsilon.mean(), self.epoch)
 
     # ------------------------------------------------------------------ checkpoints
     def save_state(self, filename):
