@@ -662,7 +662,7 @@ struct TconvParams {
     int JD, JH, JW;             // number of j positions per dim
 };
 
-template <int COT, int KD, int KH, int KW>
+template <int COT, int KD, int KH, int KW, int COC>
 __global__ void __launch_bounds__(256, 4)
 tconv3d_s2_k(const float* __restrict__ x, const float* __restrict__ wpk, const float* __restrict__ bias,
              const float* __restrict__ in_scale, const float* __restrict__ in_shift,
@@ -676,7 +676,10 @@ tconv3d_s2_k(const float* __restrict__ x, const float* __restrict__ wpk, const f
     int tile = blockIdx.x;
     const int twi = tile % p.tilesW; tile /= p.tilesW;
     const int thi = tile % p.tilesH; const int tdi = tile / p.tilesH;
-    const int CO = d.CO;
+    // COC: the layer's channel count as a compile-time constant (0 = run-time): the per-tap weight offsets t*CO then fold into the
+    // scalar loads' immediates -- with a run-time CO every one of the KVOL*CI weight loads pays 64-bit scalar address arithmetic
+    // (rocprofv3: 1855 SALU vs 930 v_pk_fma per wavefront on convt4)
+    const int CO = COC ? COC : d.CO;
     const int co0 = blockIdx.z * COT;
     const int jwl = tid % p.TJW; const int jhl = (tid / p.TJW) % p.TJH; const int jdl = tid / (p.TJW * p.TJH);
     const int jd = tdi * p.TJD + jdl, jh = thi * p.TJH + jhl, jw = twi * p.TJW + jwl;
@@ -836,7 +839,7 @@ tconv3d_s2_k(const float* __restrict__ x, const float* __restrict__ wpk, const f
     }
 }
 
-template <int COT, int KD, int KH, int KW>
+template <int COT, int KD, int KH, int KW, int COC = 0>
 int launch_tconv(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias, const float* in_scale,
                  const float* in_shift, const float* mask_src, float* y, hipStream_t s,
                  double* stats_part = nullptr, int stats_relu = 0, int stats_pg = 1, int64_t* chunks_only = nullptr) {
@@ -853,7 +856,7 @@ int launch_tconv(const vg_conv_desc* d, const float* x, const float* wpk, const 
     const int threads = vg_cdiv(p.TJW * p.TJH * p.TJD, VG_WAVE) * VG_WAVE;
     dim3 grid(p.tilesW * p.tilesH * p.tilesD, d->N, d->CO / COT);
     if (chunks_only) { *chunks_only = (int64_t)stats_pg * grid.x * (threads / VG_WAVE); return VG_OK; }
-    vg_launch(tconv3d_s2_k<COT, KD, KH, KW>, grid, dim3(threads), 0, s,
+    vg_launch(tconv3d_s2_k<COT, KD, KH, KW, COC>, grid, dim3(threads), 0, s,
               x, wpk, bias, in_scale, in_shift, mask_src, y, p, stats_part, stats_relu, stats_pg);
     return vg_check_launch("tconv3d_s2");
 }
@@ -934,7 +937,9 @@ static int tconv_dispatch(const vg_conv_desc* d, const float* x, const float* wp
     const long long pos = (long long)d->N * d->OD * d->OH * d->OW;
     const bool small = pos * d->CO < (long long)8 * 1024 * 1024;
 #define TCONV(COT, KD, KH, KW) \
-    return launch_tconv<COT, KD, KH, KW>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s, stats_part, stats_relu, stats_pg, chunks_only)
+    { if (d->CO == 8) return launch_tconv<COT, KD, KH, KW, 8>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s, stats_part, stats_relu, stats_pg, chunks_only); \
+      if (d->CO == 16) return launch_tconv<COT, KD, KH, KW, 16>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s, stats_part, stats_relu, stats_pg, chunks_only); \
+      return launch_tconv<COT, KD, KH, KW, 0>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s, stats_part, stats_relu, stats_pg, chunks_only); }
     if (d->KD == 3 && d->KH == 3 && d->KW == 3) {
         if (d->CO % 8 == 0 && !small) TCONV(8, 3, 3, 3);
         if (d->CO % 4 == 0 && small) TCONV(4, 3, 3, 3);
