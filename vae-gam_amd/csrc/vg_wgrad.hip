@@ -1140,17 +1140,8 @@ int dispatch(const vg_wgrad_desc* d, const float* a, const float* b, const float
     if (d->CB == 8 && d->CA == 1 && k333 && d->stride == 1 && d->pad_d == 0 && d->pad_h == 0 && d->pad_w == 0 &&
         d->AD >= d->PD + 2 && d->AH >= d->PH + 2)
         return launch_wide(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate);
-#define MFMA(NT, KD, KH, KW, S) \
-    return launch_mfma<NT, KD, KH, KW, S>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate)
-    if (false && d->CB <= 16 && d->PW <= 64) {
-        if (k333 && d->CA == 8 && d->stride == 1) MFMA(14, 3, 3, 3, 1);
-        if (k333 && d->CA == 8 && d->stride == 2) MFMA(14, 3, 3, 3, 2);
-        if (k333 && d->CA == 16 && d->stride == 1) MFMA(27, 3, 3, 3, 1);
-        if (k333 && d->CA == 16 && d->stride == 2) MFMA(27, 3, 3, 3, 2);
-        if (d->KD == 5 && d->KH == 3 && d->KW == 3 && d->CA == 8 && d->stride == 2) MFMA(23, 5, 3, 3, 2);
-        if (d->KD == 4 && d->KH == 4 && d->KW == 4 && d->CA == 8 && d->stride == 2) MFMA(32, 4, 4, 4, 2);
-    }
-#undef MFMA
+    // (the first-generation LDS-tile MFMA kernel, wgrad_mfma_k, is kept above for reference but no longer instantiated:
+    //  every geometry it served goes to wgrad_rows_k / wgrad_plane_k)
 #define OWN(CB, CBT, KD, KH, KW, S, TPW, OKH) \
     return launch_own<CB, CBT, KD, KH, KW, S, TPW, OKH>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate)
     if (k333 && d->CB == 16 && d->CA == 16 && d->stride == 1) { if (small_w) OWN(16, 4, 3, 3, 3, 1, 8, false); OWN(16, 4, 3, 3, 3, 1, 16, false); }
