@@ -262,3 +262,25 @@ def test_reconstruct_writes_reference_layout_and_averages(tmp_path):
         vols = [DataClass_GP.read_nifti1(str(root / s / v / 'recon_base.nii')) for v in sorted(os.listdir(root / s))]
         per_subj.append(np.mean(vols, axis=0))
     np.testing.assert_allclose(avg['base'], np.mean(per_subj, axis=0), rtol=1e-5, atol=1e-6)
+
+
+def test_bench_emits_the_contract_line():
+    """bench.py (the driver's entry point): ONE JSON line on stdout with the metric, the roofline object of the dominant
+    kernel (HIP events on the launch stream) and the CPU baseline timed in the same run."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '3', '--warmup', '2', '--cpu-steps', '1'],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in out, k
+    assert out['n_gpus'] == 1 and out['steps'] == 3 and out['dtype'] == 'f32' and out['vs_baseline'] is None
+    assert out['value'] > 1000 and 'workload' in out['config'] and 'hipGraph replay' in out['config']['workload']
+    rf = out['roofline']
+    assert rf['bound'] == 'hbm' and rf['peak'] == 8000.0 and 0 < rf['frac'] < 1 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3
+    cb = out['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['value'] > 0 and 1 <= cb['cores'] <= 16
