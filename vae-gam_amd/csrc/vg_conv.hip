@@ -36,7 +36,7 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v,
 // ------------------------------------------------------------------------------------------
 // corr3d
 // ------------------------------------------------------------------------------------------
-template <int COT, int KD, int KH, int KW, int S, int TDt, int THt, int TW>
+template <int COT, int KD, int KH, int KW, int S, int TDt, int THt, int TW, int COC>
 __global__ void __launch_bounds__(256)
 corr3d_direct_k(const float* __restrict__ x, const float* __restrict__ wpk, const float* __restrict__ bias,
          const float* __restrict__ in_scale, const float* __restrict__ in_shift,
@@ -48,7 +48,7 @@ corr3d_direct_k(const float* __restrict__ x, const float* __restrict__ wpk, cons
     const vg_conv_desc& d = p.d;
     const int tid = threadIdx.x;
     const int n = blockIdx.y;
-    const int CO = d.CO;                         // all output channels; this block computes [co0, co0+COT)
+    const int CO = COC ? COC : d.CO;             // all output channels (COC: compile-time); this block computes [co0, co0+COT)
     const int co0 = blockIdx.z * COT;
     int tile = blockIdx.x;
     const int twi = tile % p.tilesW; tile /= p.tilesW;
@@ -202,7 +202,7 @@ corr3d_direct_k(const float* __restrict__ x, const float* __restrict__ wpk, cons
     }
 }
 
-template <int COT, int KD, int KH, int KW, int S, int TDt, int THt, int TW>
+template <int COT, int KD, int KH, int KW, int S, int TDt, int THt, int TW, int COC = 0>
 int launch_corr(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias, const float* in_scale,
                 const float* in_shift, const float* mask_src, float* y, hipStream_t s) {
     CorrParams p; p.d = *d;
@@ -220,7 +220,7 @@ int launch_corr(const vg_conv_desc* d, const float* x, const float* wpk, const f
     if (d->CO % COT) { vg_set_error("corr3d: CO=%d not a multiple of %d", d->CO, COT); return VG_ERR_UNSUPPORTED; }
     const int threads = vg_cdiv(p.TWG * p.TH * p.TD, VG_WAVE) * VG_WAVE;
     dim3 grid(p.tilesW * p.tilesH * p.tilesD, d->N, d->CO / COT);
-    vg_launch(corr3d_direct_k<COT, KD, KH, KW, S, TDt, THt, TW>, grid, dim3(threads), 0, s,
+    vg_launch(corr3d_direct_k<COT, KD, KH, KW, S, TDt, THt, TW, COC>, grid, dim3(threads), 0, s,
               x, wpk, bias, in_scale, in_shift, mask_src, y, p);
     return vg_check_launch("corr3d_direct");
 }
@@ -247,7 +247,7 @@ struct CorrPlaneParams {
 };
 constexpr int PLANE_SLACK = 8;  // floats in front of the LDS buffer: a window may start at iw = -pad
 
-template <int COT, int KD, int KH, int KW, int S, int TDt, int THt, int TW>
+template <int COT, int KD, int KH, int KW, int S, int TDt, int THt, int TW, int COC>
 __global__ void __launch_bounds__(256, 3)
 corr3d_plane_k(const float* __restrict__ x, const float* __restrict__ wpk, const float* __restrict__ bias,
                const float* __restrict__ in_scale, const float* __restrict__ in_shift,
@@ -262,7 +262,7 @@ corr3d_plane_k(const float* __restrict__ x, const float* __restrict__ wpk, const
     const int tid = threadIdx.x;
     const int lane = tid % VG_WAVE, wave = vg_wave_id();
     const int n = blockIdx.y;
-    const int CO = d.CO;
+    const int CO = COC ? COC : d.CO;                 // compile-time channel count: per-tap weight offsets become load immediates
     const int co0 = blockIdx.z * COT;
     const int tdi = blockIdx.x;
     const int wg = tid % p.TWG; const int thl = (tid / p.TWG) % p.TH; const int tdl = tid / (p.TWG * p.TH);
@@ -427,7 +427,7 @@ corr3d_plane_k(const float* __restrict__ x, const float* __restrict__ wpk, const
 }
 
 // plane-staged launch; returns -1 if the geometry does not fit (caller falls back to the direct kernel)
-template <int COT, int KD, int KH, int KW, int S, int TDt, int THt, int TW>
+template <int COT, int KD, int KH, int KW, int S, int TDt, int THt, int TW, int COC = 0>
 int launch_corr_plane(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias, const float* in_scale,
                       const float* in_shift, const float* mask_src, float* y, hipStream_t s) {
     CorrPlaneParams p; p.d = *d;
@@ -462,7 +462,7 @@ int launch_corr_plane(const vg_conv_desc* d, const float* x, const float* wpk, c
     if (d->CO % COT) { vg_set_error("corr3d: CO=%d not a multiple of %d", d->CO, COT); return VG_ERR_UNSUPPORTED; }
     const int threads = vg_cdiv(p.TWG * p.TH * p.TD, VG_WAVE) * VG_WAVE;
     dim3 grid(p.tilesD, d->N, d->CO / COT);
-    vg_launch(corr3d_plane_k<COT, KD, KH, KW, S, TDt, THt, TW>, grid, dim3(threads), shmem, s,
+    vg_launch(corr3d_plane_k<COT, KD, KH, KW, S, TDt, THt, TW, COC>, grid, dim3(threads), shmem, s,
               x, wpk, bias, in_scale, in_shift, mask_src, y, p);
     return vg_check_launch("corr3d_plane");
 }
@@ -903,10 +903,17 @@ extern "C" int vg_corr3d(const vg_conv_desc* d, const float* x, const float* wpk
 #define CORR(COT, KD, KH, KW, S, TDt, THt, TW) \
     return launch_corr<COT, KD, KH, KW, S, TDt, THt, TW>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s)
 #define CORR_LDS(COT, KD, KH, KW, S, TDt, THt, TW) \
-    { int r_ = launch_corr_plane<COT, KD, KH, KW, S, TDt, THt, TW>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); \
+    { int r_ = d->CO == COT ? launch_corr_plane<COT, KD, KH, KW, S, TDt, THt, TW, COT>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s) \
+             : d->CO == 2 * COT ? launch_corr_plane<COT, KD, KH, KW, S, TDt, THt, TW, 2 * COT>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s) \
+             : launch_corr_plane<COT, KD, KH, KW, S, TDt, THt, TW, 0>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); \
       if (r_ >= 0) return r_; \
       return launch_corr<COT, KD, KH, KW, S, TDt, THt, TW>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); }
     if (!getenv("VG_NO_S1M")) { int r_ = vg_corr3d_s1_mfma(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); if (r_ >= 0) return r_; }
+#define CORR_LDS_RT(COT, KD, KH, KW, S, TDt, THt, TW) /* run-time channel count: measured faster for the 3x3x3 stride-1 8-wide instance */ \
+    { int r_ = launch_corr_plane<COT, KD, KH, KW, S, TDt, THt, TW, 0>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); \
+      if (r_ >= 0) return r_; \
+      if (d->CO == COT && !getenv("VG_DIRECT_RT")) return launch_corr<COT, KD, KH, KW, S, TDt, THt, TW, COT>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); \
+      return launch_corr<COT, KD, KH, KW, S, TDt, THt, TW>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); }
 #define CORR_MFMA(KD, KH, KW, S) \
     if (d->CI > 8 && d->CO > 8 && !getenv("VG_NO_MFMA_CONV")) { int r_ = launch_corr_mfma<KD, KH, KW, S, 8>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); if (r_ >= 0) return r_; }
     if (k333 && d->stride == 1) CORR_MFMA(3, 3, 3, 1)
@@ -916,7 +923,7 @@ extern "C" int vg_corr3d(const vg_conv_desc* d, const float* x, const float* wpk
 #undef CORR_MFMA
     if (k333 && d->stride == 1) {
         if (d->CO == 1) CORR_LDS(1, 3, 3, 3, 1, 2, 2, 4);
-        if (d->CO % 8 == 0 && !small) CORR_LDS(8, 3, 3, 3, 1, 1, 1, 4);
+        if (d->CO % 8 == 0 && !small) CORR_LDS_RT(8, 3, 3, 3, 1, 1, 1, 4);
         if (d->CO % 4 == 0 && small) CORR(4, 3, 3, 3, 1, 1, 1, 2);
     }
     if (k333 && d->stride == 2) {
