@@ -36,9 +36,9 @@ print('dispatches in trace', len(tr))
 
 # traffic keyed the way bench.py names its kernels (entry point : layer / direction), for roofline.traffic
 TABLE = {'vg_wgrad3d:convt5/bwd': 'wgrad_rows_k<1, 2, 3, 3, 3, 1, false, false', 'vg_wgrad3d:convt4/bwd': 'wgrad_rows_k<8, 3, 5, 3, 3, 2, false, false',
-         'vg_corr3d:convt4/bwd': 'corr3d_plane_k<8, 5, 3, 3, 2', 'vg_corr3d:convt5/fwd': 'corr3d_plane_k<1, 3, 3, 3, 1, 2, 2, 4>',
-         'vg_corr3d:convt5/bwd': 'corr3d_direct_k<8, 3, 3, 3, 1, 1, 1, 4>', 'vg_corr3d:convt3/fwd': 'corr3d_plane_k<8, 3, 3, 3, 1, 1, 1, 4>',
-         'vg_tconv3d_s2:convt4/fwd': 'tconv3d_s2_k<8, 5, 3, 3>', 'vg_tconv3d_s2_stats:convt4/fwd': 'tconv3d_s2_k<8, 5, 3, 3>', 'vg_wgrad3d:convt3/bwd': 'wgrad_rows_k<8, 2, 3, 3, 3, 1, false, false'}
+         'vg_corr3d:convt4/bwd': 'corr3d_plane_k<8, 5, 3, 3, 2', 'vg_corr3d:convt5/fwd': 'corr3d_plane_k<1, 3, 3, 3, 1, 2, 2, 4',
+         'vg_corr3d:convt5/bwd': 'corr3d_direct_k<8, 3, 3, 3, 1, 1, 1, 4', 'vg_corr3d:convt3/fwd': 'corr3d_plane_k<8, 3, 3, 3, 1, 1, 1, 4',
+         'vg_tconv3d_s2:convt4/fwd': 'tconv3d_s2_k<8, 5, 3, 3', 'vg_tconv3d_s2_stats:convt4/fwd': 'tconv3d_s2_k<8, 5, 3, 3', 'vg_wgrad3d:convt3/bwd': 'wgrad_rows_k<8, 2, 3, 3, 3, 1, false, false'}
 by_layer = {}
 for key, sub in TABLE.items():
     cands = [v for k, v in out.items() if sub in k]
