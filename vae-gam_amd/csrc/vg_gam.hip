@@ -203,7 +203,14 @@ adam_k(T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m, T* __restr
 // all conv / transposed-conv weights of the model -> the [ci][tap][co] images the conv kernels read through the scalar
 // path (forward and data-gradient variants), in ONE launch straight from the flat parameter buffer
 __global__ void __launch_bounds__(256)
-pack_weights_k(const float* __restrict__ flat, float* __restrict__ packed, const long long* __restrict__ segs, int nseg, long long total) {
+pack_weights_k(const float* __restrict__ flat, float* __restrict__ packed, const long long* __restrict__ gsegs, int nseg, long long total) {
+    // the segment table (a few hundred bytes) is searched per element: from LDS, not as a chain of dependent global loads
+    constexpr int MAXSEG = 64;
+    __shared__ long long ssegs[MAXSEG * 8];
+    const bool in_lds = nseg <= MAXSEG;
+    if (in_lds) for (int i = threadIdx.x; i < nseg * 8; i += blockDim.x) ssegs[i] = gsegs[i];
+    __syncthreads();
+    const long long* segs = in_lds ? ssegs : gsegs;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         int sgi = 0;
         while (sgi + 1 < nseg && e >= segs[(sgi + 1) * 8 + 1]) ++sgi;            // segments are sorted by destination offset
