@@ -174,8 +174,12 @@ int vg_cholesky_f64(const double* a, double* l, int32_t batch, int32_t n, void* 
 
 /* fused Adam (torch.optim.Adam defaults, vae_reg_GP.py:179,429) over one flat buffer:
  * p,g,m,v: n elements of fp32 (is_f64 = 0) or fp64 (is_f64 = 1).  step_size = lr/(1-b1^t),
- * bc2_sqrt = sqrt(1-b2^t) are passed as device scalars [2] so a captured graph can replay
- * with a changing step count. */
+ * bc2_sqrt = sqrt(1-b2^t) are read from device scalars step_scalars[0..1] so a captured graph can replay
+ * with a changing step count.
+ * vg_adam_advance keeps that count ON THE DEVICE: state = double[3] {step_size, bc2_sqrt, t}; one launch does
+ * t += 1 and refreshes the two scalars (torch.optim.Adam's per-step `step += 1` and bias corrections).  Launched
+ * inside the step (and captured with it), so queued replays can never see a later step's scalars. */
+int vg_adam_advance(double* state, double lr, double b1, double b2, void* stream);
 int vg_adam_step(void* p, const void* g, void* m, void* v, int64_t n, int32_t is_f64,
                  double b1, double b2, double eps, const double* step_scalars, void* stream);
 

@@ -215,21 +215,17 @@ def run_fused_stats_case(dev, spec, isz, groups=2, per_group=3, seed=0):
     b = torch.randn(spec.co, generator=g).to(dev)
     gamma = (1 + 0.1 * torch.randn(spec.co, generator=g)).to(dev); beta = (0.1 * torch.randn(spec.co, generator=g)).to(dev)
     wf = ops.pack_weight(w, spec, 'fwd')
-    y = ops.conv_forward(x, wf, b, spec, True, None, None, per_group, next_bn=per_group)
-    assert ops._STATS, 'the stride-2 transposed-conv path must leave statistics partials'
-    fused = [t.clone() for t in ops.bn_stats(y, gamma, beta, True, per_group)]
-    assert not ops._STATS
+    y, part = ops.conv_forward(x, wf, b, spec, True, None, None, per_group, next_bn=per_group)   # explicit hand-off
+    fused = [t.clone() for t in ops.bn_stats(y, gamma, beta, True, per_group, pre=part)]
     plain = ops.bn_stats(y, gamma, beta, True, per_group)
     for a_, b_, nm in zip(fused, plain, ('scale', 'shift', 'mean', 'rstd')):
         np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=nm)
     # fused bias-gradient sum of the batch-norm backward
     dxe = torch.randn(y.shape, generator=g).to(dev)
-    ops.bn_backward_(dxe, y, gamma, plain[2], plain[3], True, per_group)
-    pre = ops._CHSUM.get(ops._chsum_key(dxe))
-    assert pre is not None
-    want = dxe.sum((0, 2, 3, 4))
-    np.testing.assert_allclose(pre.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(want.abs().max()))
-    ops._CHSUM.clear()
+    pbg = torch.full((spec.co,), 0.5, device=dev)             # the producing layer's bias.grad: the sum is ADDED to it
+    ops.bn_backward_(dxe, y, gamma, plain[2], plain[3], True, per_group, producer_bias_grad=pbg)
+    want = dxe.sum((0, 2, 3, 4)) + 0.5
+    np.testing.assert_allclose(pbg.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(want.abs().max()))
 
 
 def run_adam_case(dev, dtype, n=5000, steps=3, seed=0):
@@ -241,7 +237,11 @@ def run_adam_case(dev, dtype, n=5000, steps=3, seed=0):
     for t in range(1, steps + 1):
         gr = torch.randn(n, generator=g, dtype=dtype)
         ref.grad = gr.clone(); opt.step()
-        sc = torch.tensor([1e-3 / (1 - 0.9 ** t), np.sqrt(1 - 0.999 ** t)], dtype=torch.float64, device=dev)
+        if t == 1:
+            sc = torch.zeros(3, dtype=torch.float64, device=dev)
+        ops.adam_advance_(sc, 1e-3, 0.9, 0.999)                   # device-side step count + bias-correction scalars
+        want_sc = [1e-3 / (1 - 0.9 ** t), np.sqrt(1 - 0.999 ** t), float(t)]
+        np.testing.assert_allclose(sc.cpu().numpy(), want_sc, rtol=1e-14)
         ops.adam_step_(p, gr.to(dev), m, v, 0.9, 0.999, 1e-8, sc)
     tol = 1e-6 if dtype == torch.float32 else 1e-12
     np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=tol, atol=tol)

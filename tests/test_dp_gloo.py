@@ -56,7 +56,7 @@ def _rank_main(rank, world, port, out_dir):
 def restore_library():
     prev = _lib._LIB
     yield
-    _lib.set_library_for_tests(prev)
+    _lib._LIB = prev
 
 
 def test_two_ranks_equal_one_rank_global_batch(tmp_path):

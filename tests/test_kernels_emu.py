@@ -16,16 +16,10 @@ EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'emu')
 
 @pytest.fixture(scope='module', autouse=True)
 def emu_lib():
-    so = os.path.join(EMU_DIR, 'libvaegam_emu.so')
-    srcs = [os.path.join(EMU_DIR, f) for f in os.listdir(EMU_DIR) if f.endswith(('.h', '.cpp', '.sh'))]
-    csrc = os.path.join(os.path.dirname(EMU_DIR), '..', 'vae-gam_amd', 'csrc')
-    srcs += [os.path.join(csrc, f) for f in os.listdir(csrc)]
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.check_call([os.path.join(EMU_DIR, 'build_emu.sh')])
-    prev = _lib._LIB
-    _lib.set_library_for_tests(_lib.VgLibrary(so))
+    import emu_inject
+    prev = emu_inject.inject_emu()
     yield
-    _lib.set_library_for_tests(prev)
+    emu_inject.restore(prev)
 
 
 @pytest.mark.parametrize('name,spec,isz', K.LAYERS, ids=[l[0] for l in K.LAYERS])

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope='module', autouse=True)
 def hip_lib():
     assert torch.cuda.is_available(), 'GPU tests need a GPU'
-    _lib.set_library_for_tests(None)
+    import emu_inject; emu_inject.use_product_library()
     lib = _lib.get_lib()                       # raises if libvaegam_hip.so is missing: no fallback
     assert lib.path.endswith('libvaegam_hip.so')
     yield

@@ -16,7 +16,7 @@ def emu():
     prev = _lib._LIB
     T.load_emu_library()
     yield
-    _lib.set_library_for_tests(prev)
+    _lib._LIB = prev
 
 
 def test_train_step_matches_oracle_toy_geometry():

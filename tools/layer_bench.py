@@ -7,7 +7,7 @@ import torch
 import vae_gam_amd
 from vae_gam_amd import ops, _lib
 if os.environ.get('VG_LIB'):
-    _lib.set_library_for_tests(_lib.VgLibrary(os.environ['VG_LIB']))     # diagnostic builds (ablations)
+    _lib._LIB = _lib.VgLibrary(os.environ['VG_LIB'])     # diagnostic builds (ablations)
 from vae_gam_amd.schema import net_geometry
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32

@@ -2,8 +2,8 @@
 
 The product path loads ONLY the hipcc-built library that sits next to this file and fails
 loudly if it is missing -- there is no CPU fallback.  (`tests/emu` builds the same sources
-for the host to debug index arithmetic; tests inject that handle explicitly through
-`set_library_for_tests`, the product never looks for it.)
+for the host to debug index arithmetic; the test-side helper tests/emu_inject.py swaps that
+handle in by monkeypatching this module, the product never looks for it.)
 """
 import ctypes
 import os
@@ -54,6 +54,7 @@ _PROTOS = {
     'vg_gam_elbo_bwd': (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, vp]),
     'vg_pack_weights': (ctypes.c_int, [vp, vp, vp, i32, i64, vp]),
     'vg_cholesky_f64': (ctypes.c_int, [vp, vp, i32, i32, vp]),
+    'vg_adam_advance': (ctypes.c_int, [vp, f64, f64, f64, vp]),
     'vg_adam_step': (ctypes.c_int, [vp, vp, vp, vp, i64, i32, f64, f64, f64, vp, vp]),
 }
 EXPORTS = tuple(_PROTOS)
@@ -64,6 +65,8 @@ class VgError(RuntimeError):
 
 
 class VgLibrary:
+    host_pointers_ok = False        # the hipcc-built library dereferences DEVICE pointers only
+
     def __init__(self, path):
         if not os.path.exists(path):
             raise VgError('HIP kernel library %s not found: run `python -c "import __graft_entry__ as g; g.build()"` '
@@ -87,7 +90,6 @@ class VgLibrary:
 
 
 _LIB = None
-_INJECTED = False
 
 
 def library_path():
@@ -99,14 +101,3 @@ def get_lib() -> VgLibrary:
     if _LIB is None:
         _LIB = VgLibrary(library_path())
     return _LIB
-
-
-def set_library_for_tests(lib):
-    """tests only: inject a handle (e.g. the host build of the kernels under tests/emu)."""
-    global _LIB, _INJECTED
-    _LIB = lib
-    _INJECTED = lib is not None
-
-
-def test_library_injected():
-    return _INJECTED

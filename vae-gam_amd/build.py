@@ -36,8 +36,13 @@ def build_hip(force=False, verbose=True):
     os.makedirs(objdir, exist_ok=True)
     flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
 
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + [os.path.join(HERE, '..', 'include', 'vaegam.h')]
+    hdr_t = max(os.path.getmtime(h) for h in headers)
+
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + '.o')
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(hdr_t, os.path.getmtime(os.path.join(CSRC, src))):
+            return obj                                   # object newer than its source and every header: keep it
         cmd = [hipcc] + flags + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print('[vae_gam_amd.build]', ' '.join(cmd), flush=True)

@@ -199,6 +199,17 @@ adam_k(T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m, T* __restr
     }
 }
 
+// One thread: advance the optimiser's step count ON THE DEVICE and derive the two bias-correction scalars adam_k reads.
+// st = [step_size, bc2_sqrt, t].  Living inside the (captured) step, the count can never run ahead of the launches that
+// use it -- a host-staged scalar buffer rewritten for step t+1 could be read by step t's still-queued kernels.
+__global__ void adam_advance_k(double* __restrict__ st, double lr, double b1, double b2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double t = st[2] + 1.0;
+    st[2] = t;
+    st[0] = lr / (1.0 - pow(b1, t));
+    st[1] = sqrt(1.0 - pow(b2, t));
+}
+
 // ---------------------------------------------------------------------------------- weight packing
 // all conv / transposed-conv weights of the model -> the [ci][tap][co] images the conv kernels read through the scalar
 // path (forward and data-gradient variants), in ONE launch straight from the flat parameter buffer
@@ -289,6 +300,12 @@ extern "C" int vg_gam_elbo_bwd(const float* logits, const float* gain, const flo
     }
     vg_launch(gam_bwd_fold_eps_k, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, s, (const float*)part_dsig, eps, BS, (long long)V, d_eps);
     return vg_check_launch("gam_bwd_fold_eps");
+}
+
+extern "C" int vg_adam_advance(double* state, double lr, double b1, double b2, void* stream) {
+    if (!state || !(lr > 0) || !(b1 >= 0 && b1 < 1) || !(b2 >= 0 && b2 < 1)) { vg_set_error("vg_adam_advance: bad arguments"); return VG_ERR_ARG; }
+    vg_launch(adam_advance_k, dim3(1), dim3(64), 0, (hipStream_t)stream, state, lr, b1, b2);
+    return vg_check_launch("adam_advance");
 }
 
 extern "C" int vg_adam_step(void* p, const void* g, void* m, void* v, int64_t n, int32_t is_f64,

@@ -42,7 +42,7 @@ class label:
 def _call(t, fn, *args):
     """Launch one C-ABI entry point on t's current stream (optionally bracketed by HIP events)."""
     lib = _lib.get_lib()
-    if not t.is_cuda and not _lib.test_library_injected():
+    if not t.is_cuda and not lib.host_pointers_ok:
         raise RuntimeError('refusing to launch %s on a non-GPU tensor: the HIP kernels need device pointers (no CPU path)' % fn)
     if PROFILE is not None and t.is_cuda:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -214,15 +214,11 @@ def _conv_desc(N, ci, co, isz, osz, k, stride, pad, relu_in, per_group):
                     pad[0], pad[1], pad[2], int(relu_in), int(per_group))
 
 
-# batch statistics of a layer output that the kernel producing it already accumulated (keyed by the output's storage):
-# (partials, chunks, relu, per_group) for the NEXT layer's bn_stats
-_STATS = {}
-
-
 def conv_forward(x, wpk, bias, spec: ConvSpec, relu_in=False, scale=None, shift=None, per_group=1, next_bn=None):
     """Layer forward: y = conv/convT(P(x)) + bias, y is the pre-activation.
-    next_bn = per_group of the BatchNorm3d that consumes relu(y): the stride-2 transposed-conv kernel then also leaves the
-    statistics partials for it (no separate pass over y)."""
+    next_bn = per_group of the BatchNorm3d that consumes relu(y): the stride-2 transposed-conv kernel then also accumulates
+    the statistics partials for it (no separate pass over y) and the call returns (y, partials) -- the caller hands the
+    partials to the consuming layer's bn_stats(pre=...) explicitly."""
     lib = _lib.get_lib()
     N = x.shape[0]
     isz = tuple(x.shape[2:]); osz = spec.out_size(isz)
@@ -244,10 +240,11 @@ def conv_forward(x, wpk, bias, spec: ConvSpec, relu_in=False, scale=None, shift=
             part = torch.empty(G * spec.co * chunks * 2, dtype=torch.float64, device=x.device)
             _call(x, 'vg_tconv3d_s2_stats', ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(scale), _p(shift), _p(y), int(next_bn), 1,
                      _p(part))
-            _STATS.clear()
-            _STATS[_chsum_key(y)] = (part, chunks, True, int(next_bn))
+            return y, part
         else:
             _call(x, 'vg_tconv3d_s2', ctypes.byref(d), _p(x), _p(wpk), _p(bias), _p(scale), _p(shift), None, _p(y))
+    if next_bn:
+        raise ValueError('next_bn: only the stride-2 transposed-conv kernel accumulates the next layer\'s statistics')
     return y
 
 
@@ -303,17 +300,21 @@ def _bn_ws(x, N, C, P, per_group):
     return torch.empty(nbytes // 8, dtype=torch.float64, device=x.device)
 
 
-def bn_stats(x, gamma, beta, relu, per_group, sync=None):
+def bn_stats(x, gamma, beta, relu, per_group, sync=None, pre=None):
     """Batch statistics of relu?(x) per (group, channel) -> (scale, shift, mean, rstd), each [G*C].
-    `sync(t)` (optional) all-reduces the raw [sum, sumsq, count] triples across data-parallel ranks."""
+    `sync(t)` (optional) all-reduces the raw [sum, sumsq, count] triples across data-parallel ranks.
+    `pre`: the partials of relu(x) with THIS per_group that the kernel which wrote x accumulated
+    (conv_forward(..., next_bn=per_group)); x is then not read at all."""
     lib = _lib.get_lib()
     N, C = x.shape[0], x.shape[1]
     P = x[0, 0].numel()
     G = N // per_group
     out = torch.empty((4, G * C), dtype=torch.float32, device=x.device)
-    pre = _STATS.pop(_chsum_key(x), None)
-    if pre is not None and pre[2] == bool(relu) and pre[3] == per_group and pre[0].device == x.device:
-        part, chunks = pre[0], pre[1]                      # accumulated by the kernel that wrote x
+    if pre is not None:
+        assert relu, 'producer-side partials are statistics of relu(x)'
+        part = pre
+        assert part.dtype == torch.float64 and part.device == x.device and part.numel() % (G * C * 2) == 0
+        chunks = part.numel() // (G * C * 2)
         sums = torch.empty((G * C, 3), dtype=torch.float64, device=x.device)
         count = float(per_group * P)
         if sync is None:
@@ -347,19 +348,12 @@ def _grad_buf(t):
     return None
 
 
-# per-channel sums of a data gradient that the kernel producing it already formed (keyed by the gradient's storage):
-# the next backward node takes its bias gradient from here instead of re-reading the whole tensor
-_CHSUM = {}
-
-
-def _chsum_key(t):
-    return (t.data_ptr(), tuple(t.shape))
-
-
-def bn_backward_(dxe, p, gamma, mean, rstd, relu, per_group, sync=None, beta=None):
+def bn_backward_(dxe, p, gamma, mean, rstd, relu, per_group, sync=None, beta=None, producer_bias_grad=None):
     """In place: dxe (grad w.r.t. the normalised tensor) -> grad w.r.t. the stored pre-activation p.
     Returns (dgamma[C], dbeta[C]) summed over groups -- or (None, None) after adding them straight into
-    gamma.grad / beta.grad when both exist (one launch instead of autograd's two sums + two adds)."""
+    gamma.grad / beta.grad when both exist (one launch instead of autograd's two sums + two adds).
+    producer_bias_grad [C] (optional): += the per-channel sum of the result, i.e. the bias gradient of the layer that
+    produced p, from the values the apply pass already holds (that layer then skips its own channel-sum pass)."""
     lib = _lib.get_lib()
     N, C = p.shape[0], p.shape[1]
     P = p[0, 0].numel()
@@ -375,11 +369,10 @@ def bn_backward_(dxe, p, gamma, mean, rstd, relu, per_group, sync=None, beta=Non
         sums = sync(sums)
         count = count * sync.world_size
     parts = torch.empty((2, G, C), dtype=torch.float32, device=p.device)
-    chs = torch.empty(C, dtype=torch.float32, device=p.device)
+    if producer_bias_grad is not None:
+        assert producer_bias_grad.shape == (C,) and producer_bias_grad.is_contiguous() and producer_bias_grad.dtype == torch.float32
     _call(p, 'vg_bn_bwd_apply', _p(dxe), _p(p), N, C, P, per_group, int(relu), _p(gamma), _p(mean), _p(rstd), _p(sums),
-             count, _p(parts[0]), _p(parts[1]), _p(ws), _p(chs), 0)
-    _CHSUM.clear()
-    _CHSUM[_chsum_key(dxe)] = chs
+             count, _p(parts[0]), _p(parts[1]), _p(ws), _p(producer_bias_grad), 1)
     src = local if local is not None else sums      # data parallel: this rank's share (the gradient all-reduce sums them)
     gg, bg = _grad_buf(gamma), _grad_buf(beta)
     if gg is not None and bg is not None:
@@ -391,12 +384,6 @@ def bn_backward_(dxe, p, gamma, mean, rstd, relu, per_group, sync=None, beta=Non
 
 
 def channel_sum(x, out=None):
-    pre = _CHSUM.pop(_chsum_key(x), None)
-    if pre is not None and pre.device == x.device:         # already summed by the batch-norm backward that produced x
-        if out is not None:
-            out.add_(pre)
-            return None
-        return pre
     lib = _lib.get_lib()
     N, C = x.shape[0], x.shape[1]
     P = x[0, 0].numel()
@@ -418,31 +405,48 @@ class BnConvAct(torch.autograd.Function):
     backward : channel_sum (bias), wgrad3d, data gradient (+ fused ReLU mask), [bn backward]
     `input_is_data=True` (first encoder layer): no data gradient is formed; the batch-norm
     parameter gradients follow from the weight gradient (valid conv, every tap hits the input).
+
+    Two explicit hand-offs between neighbouring layers (arguments, no state outside the nodes):
+      forward   `next_bn`   : this (stride-2 transposed-conv) layer also accumulates the statistics partials of the
+                              BatchNorm3d that consumes its output; returned as a second output, which the caller passes
+                              to that layer as `pre_stats`;
+      backward  `producer_bias` : Parameter (bias of the layer that produced p_in).  This layer's batch-norm backward adds
+                              the per-channel sum of the gradient it hands back straight into producer_bias.grad, and the
+                              producing layer is built with `bias_grad_by_consumer=True` so that it skips its own pass.
     """
 
     @staticmethod
     def forward(ctx, p_in, weight, bias, gamma, beta, spec: ConvSpec, relu_in: bool, per_group: int,
-                input_is_data: bool, sync, packed=None, next_bn=None):
+                input_is_data: bool, sync, packed=None, next_bn=None, pre_stats=None, producer_bias=None,
+                bias_grad_by_consumer=False):
         p_in = p_in.contiguous()
-        _CHSUM.clear()                                   # sums handed over between backward nodes never outlive a backward pass
         has_bn = gamma is not None
+        assert producer_bias is None or has_bn, 'producer_bias: the hand-off happens in the batch-norm backward'
         scale = shift = mean = rstd = None
+        part = None
         with label(spec.name + '/fwd'):
             if has_bn:
-                scale, shift, mean, rstd = bn_stats(p_in, gamma, beta, relu_in, per_group, sync)
+                scale, shift, mean, rstd = bn_stats(p_in, gamma, beta, relu_in, per_group, sync, pre_stats)
             wf = packed.get(spec.name, 'fwd') if packed is not None else pack_weight(weight, spec, 'fwd')
             y = conv_forward(p_in, wf, bias, spec, relu_in, scale, shift, per_group, next_bn)
+            if next_bn:
+                y, part = y
         ctx.spec, ctx.relu_in, ctx.per_group, ctx.input_is_data, ctx.sync, ctx.has_bn = \
             spec, relu_in, per_group, input_is_data, sync, has_bn
         ctx.save_for_backward(p_in, weight, gamma, beta, scale, shift, mean, rstd)
         ctx.bias_ref = bias
         ctx.packed = packed
+        ctx.producer_bias, ctx.bias_grad_by_consumer = producer_bias, bool(bias_grad_by_consumer)
+        ctx.nout = 2 if next_bn else 1
+        if next_bn:
+            ctx.mark_non_differentiable(part)
+            return y, part
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
         with label(ctx.spec.name + '/bwd'):
-            return BnConvAct._backward(ctx, dy)
+            return BnConvAct._backward(ctx, dy) + (None, None, None)
 
     @staticmethod
     def _backward(ctx, dy):
@@ -456,11 +460,15 @@ class BnConvAct(torch.autograd.Function):
         bg = bias_t.grad if (isinstance(bias_t, torch.nn.Parameter) and bias_t.grad is not None and bias_t.grad.is_contiguous()) else None
         direct_db = bg is not None and not (ctx.input_is_data and ctx.has_bn)
         overlap = direct_db and wg is not None and not ctx.input_is_data
+        skip_db = ctx.bias_grad_by_consumer            # the consuming layer's batch-norm backward already added it to bias.grad
         if overlap:
             with on_side_stream(dy, dy, p_in, scale, shift, wg, bg):
-                channel_sum(dy, out=bg)
+                if not skip_db:
+                    channel_sum(dy, out=bg)
                 conv_weight_grad(p_in, dy, spec, relu_in, scale, shift, per_group, out=wg)
             db = dw = None
+        elif skip_db:
+            db = None
         else:
             db = channel_sum(dy, out=bg) if direct_db else channel_sum(dy)
         dgamma = dbeta = dp = None
@@ -485,17 +493,25 @@ class BnConvAct(torch.autograd.Function):
         in_size = tuple(p_in.shape[2:])
         if ctx.has_bn:
             dp = conv_backward_data(dy, wb, spec, in_size, None)
-            dgamma, dbeta = bn_backward_(dp, p_in, gamma, mean, rstd, relu_in, per_group, ctx.sync, beta)
+            pbg = None
+            if ctx.producer_bias is not None:
+                pb = ctx.producer_bias
+                if pb.grad is None:
+                    pb.grad = torch.zeros_like(pb)
+                pbg = pb.grad
+            dgamma, dbeta = bn_backward_(dp, p_in, gamma, mean, rstd, relu_in, per_group, ctx.sync, beta, pbg)
         else:
             dp = conv_backward_data(dy, wb, spec, in_size, p_in if relu_in else None)
         return dp, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def bn_conv_act(p_in, weight, bias, gamma, beta, spec, relu_in, per_group=None, input_is_data=False, sync=None, packed=None,
-                next_bn=None):
+                next_bn=None, pre_stats=None, producer_bias=None, bias_grad_by_consumer=False):
+    """-> y, or (y, statistics partials for the consuming BatchNorm3d) when next_bn is given."""
     if per_group is None:
         per_group = p_in.shape[0]
-    return BnConvAct.apply(p_in, weight, bias, gamma, beta, spec, relu_in, per_group, input_is_data, sync, packed, next_bn)
+    return BnConvAct.apply(p_in, weight, bias, gamma, beta, spec, relu_in, per_group, input_is_data, sync, packed, next_bn,
+                           pre_stats, producer_bias, bias_grad_by_consumer)
 
 
 class GamElbo(torch.autograd.Function):
@@ -749,9 +765,14 @@ class CholeskyF64(torch.autograd.Function):
 
 def cholesky(a):
     """Batched lower Cholesky factor; the HIP kernel for float64 n <= 128, torch otherwise."""
-    if a.dtype == torch.float64 and a.shape[-1] <= 128 and (a.is_cuda or _lib.test_library_injected()):
+    if a.dtype == torch.float64 and a.shape[-1] <= 128 and (a.is_cuda or _lib.get_lib().host_pointers_ok):
         return CholeskyF64.apply(a)
     return torch.linalg.cholesky_ex(a, check_errors=False).L
+
+
+def adam_advance_(state, lr, b1, b2):
+    """state = double[3] {lr/(1-b1^t), sqrt(1-b2^t), t} on the device: t += 1, scalars refreshed (one thread)."""
+    _call(state, 'vg_adam_advance', _p(_chk(state, torch.float64)), float(lr), float(b1), float(b2))
 
 
 def adam_step_(p, g, m, v, b1, b2, eps, step_scalars):

@@ -66,10 +66,10 @@ class FusedAdam:
                 p.grad = flat_g[offs[k]:offs[k] + sizes[k]].view(p.shape)
             self.groups[dtype] = dict(idx=idx, offs=offs, sizes=sizes, p=flat_p, g=flat_g,
                                       m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p))
-        self._scalars = torch.zeros(2, dtype=torch.float64, device=device)
-        self._scalars_host = torch.zeros(2, dtype=torch.float64)
-        if device.type == 'cuda':
-            self._scalars_host = self._scalars_host.pin_memory()
+        # [lr/(1-b1^t), sqrt(1-b2^t), t] ON THE DEVICE, advanced by a one-thread kernel inside the step (vg_adam_advance): a
+        # host-staged buffer rewritten per step could be overwritten for step t+1 while step t's launches (or hipGraph
+        # replays) that read it are still queued.  `step_count` is the host's mirror of t (checkpoints, state_dict).
+        self._scalars = torch.zeros(3, dtype=torch.float64, device=device)
 
     def group_views(self, names):
         """(parameters, gradients) of a contiguous group as flat 1-D views of the flat buffers, or None."""
@@ -102,21 +102,22 @@ class FusedAdam:
                 if p.grad is None or p.grad.data_ptr() != gr['g'].data_ptr() + gr['offs'][k] * gr['g'].element_size():
                     p.grad = gr['g'][gr['offs'][k]:gr['offs'][k] + gr['sizes'][k]].view(p.shape)
 
-    def prepare_step_scalars(self):
-        """Host side of a step: advance t and stage [lr/(1-b1^t), sqrt(1-b2^t)] for the kernel.
-        Kept outside `apply_update` so that a captured hipGraph can replay with a moving step count."""
+    def advance(self):
+        """t += 1 and the bias-correction scalars, on the device, as a launch of its own (captured with the step)."""
+        ops.adam_advance_(self._scalars, self.lr, self.betas[0], self.betas[1])
         self.step_count += 1
-        t = self.step_count
-        self._scalars_host[0] = self.lr / (1.0 - self.betas[0] ** t)
-        self._scalars_host[1] = math.sqrt(1.0 - self.betas[1] ** t)
-        self._scalars.copy_(self._scalars_host, non_blocking=True)
+
+    def set_step_count(self, t):
+        """Resume / restore: put the device-side count at t (outside any capture)."""
+        self.step_count = int(t)
+        self._scalars.copy_(torch.tensor([0.0, 0.0, float(t)], dtype=torch.float64))
 
     def apply_update(self):
         for g in self.groups.values():
             ops.adam_step_(g['p'], g['g'], g['m'], g['v'], self.betas[0], self.betas[1], self.eps, self._scalars)
 
     def step(self):
-        self.prepare_step_scalars()
+        self.advance()
         self.apply_update()
 
     # ---- checkpoint format of torch.optim.Adam
@@ -158,4 +159,4 @@ class FusedAdam:
             steps.add(int(float(st['step'])))
         if len(steps) > 1:
             raise ValueError('per-parameter Adam step counts differ (%s): not representable by the fused optimiser' % sorted(steps))
-        self.step_count = steps.pop() if steps else 0
+        self.set_step_count(steps.pop() if steps else 0)

@@ -243,7 +243,7 @@ class VAE(nn.Module):
     def _require_gpu(self, t):
         if not t.is_cuda:
             from . import _lib
-            if not _lib.test_library_injected():
+            if not _lib.get_lib().host_pointers_ok:
                 raise RuntimeError('vae_gam_amd runs the VAE-GAM step on HIP kernels only: tensors must be on an MI355X '
                                    '(device "cuda"); there is no CPU path.')
 
@@ -257,11 +257,15 @@ class VAE(nn.Module):
         B = x.shape[0]
         h = x.reshape(B, 1, *self.img_shape).contiguous()
         s = self._sync()
-        p = ops.bn_conv_act(h, self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias, e[0], False, B, True, s, self._packed)
-        p = ops.bn_conv_act(p, self.conv2.weight, self.conv2.bias, None, None, e[1], True, B, False, s, self._packed)
-        p = ops.bn_conv_act(p, self.conv3.weight, self.conv3.bias, self.bn3.weight, self.bn3.bias, e[2], True, B, False, s, self._packed)
-        p = ops.bn_conv_act(p, self.conv4.weight, self.conv4.bias, None, None, e[3], True, B, False, s, self._packed)
-        p = ops.bn_conv_act(p, self.conv5.weight, self.conv5.bias, self.bn5.weight, self.bn5.bias, e[4], True, B, False, s, self._packed)
+        bca = ops.bn_conv_act
+        # bias gradients of conv2 / conv4 come out of the batch-norm backward of the layers that consume them (bn3 / bn5)
+        p = bca(h, self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias, e[0], False, B, True, s, self._packed)
+        p = bca(p, self.conv2.weight, self.conv2.bias, None, None, e[1], True, B, False, s, self._packed, bias_grad_by_consumer=True)
+        p = bca(p, self.conv3.weight, self.conv3.bias, self.bn3.weight, self.bn3.bias, e[2], True, B, False, s, self._packed,
+                producer_bias=self.conv2.bias)
+        p = bca(p, self.conv4.weight, self.conv4.bias, None, None, e[3], True, B, False, s, self._packed, bias_grad_by_consumer=True)
+        p = bca(p, self.conv5.weight, self.conv5.bias, self.bn5.weight, self.bn5.bias, e[4], True, B, False, s, self._packed,
+                producer_bias=self.conv4.bias)
         return p
 
     def encode(self, x):
@@ -298,11 +302,18 @@ class VAE(nn.Module):
         la = ops.linear_act
         h = la(self.fc7, la(self.fc6, la(self.fc5, z, True), True), True)
         p = la(self.fc8, h, False).view(-1, 2 * self.nf, *self.geom.dec_seed)   # ReLU applied by convt1's loader
-        p = ops.bn_conv_act(p, self.convt1.weight, self.convt1.bias, self.bnt1.weight, self.bnt1.bias, dsp[0], True, per_group, False, s, self._packed)
-        p = ops.bn_conv_act(p, self.convt2.weight, self.convt2.bias, None, None, dsp[1], True, per_group, False, s, self._packed, per_group)   # + bnt3's statistics
-        p = ops.bn_conv_act(p, self.convt3.weight, self.convt3.bias, self.bnt3.weight, self.bnt3.bias, dsp[2], True, per_group, False, s, self._packed)
-        p = ops.bn_conv_act(p, self.convt4.weight, self.convt4.bias, None, None, dsp[3], True, per_group, False, s, self._packed, per_group)   # + bnt5's statistics
-        p = ops.bn_conv_act(p, self.convt5.weight, self.convt5.bias, self.bnt5.weight, self.bnt5.bias, dsp[4], True, per_group, False, s, self._packed)
+        bca = ops.bn_conv_act
+        # explicit hand-offs between neighbouring layers (ops.BnConvAct): convt2 / convt4 also accumulate the statistics of
+        # bnt3 / bnt5 (st3, st5); the bias gradients of convt2 / convt4 come out of bnt3's / bnt5's backward
+        p = bca(p, self.convt1.weight, self.convt1.bias, self.bnt1.weight, self.bnt1.bias, dsp[0], True, per_group, False, s, self._packed)
+        p, st3 = bca(p, self.convt2.weight, self.convt2.bias, None, None, dsp[1], True, per_group, False, s, self._packed,
+                     next_bn=per_group, bias_grad_by_consumer=True)
+        p = bca(p, self.convt3.weight, self.convt3.bias, self.bnt3.weight, self.bnt3.bias, dsp[2], True, per_group, False, s, self._packed,
+                pre_stats=st3, producer_bias=self.convt2.bias)
+        p, st5 = bca(p, self.convt4.weight, self.convt4.bias, None, None, dsp[3], True, per_group, False, s, self._packed,
+                     next_bn=per_group, bias_grad_by_consumer=True)
+        p = bca(p, self.convt5.weight, self.convt5.bias, self.bnt5.weight, self.bnt5.bias, dsp[4], True, per_group, False, s, self._packed,
+                pre_stats=st5, producer_bias=self.convt4.bias)
         return p.reshape(p.shape[0], self.img_dim)
 
     def decode(self, z):
@@ -524,20 +535,19 @@ class VAE(nn.Module):
                 fresh = self.draw_noise(Bg, x.device)                   # same draws, same order as the eager path
                 for k in fresh:
                     g['noise'][k].copy_(fresh[k])
-                self.optimizer.prepare_step_scalars()
-                g['graph'].replay()
+                g['graph'].replay()                                     # includes the device-side Adam step-count advance
+                self.optimizer.step_count += 1                          # host mirror of the device count
                 return g['loss']
         return self._train_step_eager(ids, covariates, x, noise)
 
-    def _train_step_eager(self, ids, covariates, x, noise=None, advance=True):
+    def _train_step_eager(self, ids, covariates, x, noise=None):
         self.optimizer.zero_grad()
         loss = self.forward(ids, covariates, x, 'train', train_mode=True, noise=noise)
         loss.backward()
         ops.join_side_stream(x.device)                      # weight / bias gradient kernels run on a second stream
         if self.dp is not None:
             self.dp.allreduce_grads(self.optimizer.flat_grads())
-        if advance:
-            self.optimizer.prepare_step_scalars()
+        self.optimizer.advance()
         self.optimizer.apply_update()
         loss = loss.detach()
         if self.dp is not None:
@@ -554,6 +564,7 @@ class VAE(nn.Module):
         # graph does not change the training trajectory (the capture itself executes nothing)
         snap = [(g, g['p'].clone(), g['m'].clone(), g['v'].clone()) for g in self.optimizer.groups.values()]
         step0 = self.optimizer.step_count
+        torch.cuda.current_stream(x.device).synchronize()       # everything queued so far has used the device-side count
         rng = torch.cuda.get_rng_state(x.device)
         try:
             st['noise'] = self.draw_noise(x.shape[0] * (1 if self.dp is None else self.dp.world_size), x.device)
@@ -565,10 +576,10 @@ class VAE(nn.Module):
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                st['loss'] = self._train_step_eager(st['ids'], st['cov'], st['x'], noise=st['noise'], advance=False)
+                st['loss'] = self._train_step_eager(st['ids'], st['cov'], st['x'], noise=st['noise'])
             for g, p0, m0, v0 in snap:
                 g['p'].copy_(p0); g['m'].copy_(m0); g['v'].copy_(v0)
-            self.optimizer.step_count = step0
+            self.optimizer.set_step_count(step0)
             torch.cuda.set_rng_state(rng, x.device)
             st['graph'] = graph
             self._graphs[key] = st
@@ -578,7 +589,7 @@ class VAE(nn.Module):
             torch.cuda.synchronize()
             for g, p0, m0, v0 in snap:
                 g['p'].copy_(p0); g['m'].copy_(m0); g['v'].copy_(v0)
-            self.optimizer.step_count = step0
+            self.optimizer.set_step_count(step0)
             torch.cuda.set_rng_state(rng, x.device)
         if self.dp is not None:
             # every rank must make the same choice (a graph replays its collectives, an eager rank issues them one by one)
