@@ -4,17 +4,24 @@
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
 torch.distributed.run with one rank per GPU.  Prints ONE JSON line on rank 0.
 
-Workload (`config.workload`): BASELINE.json configs[1] -- synthetic checker-control set
-(2 subjects x 98 volumes of 41x49x35, 'Large3' control signal), 3 covariates [task, x, y],
-batch 32 PER GPU (weak scaling), random-init weights (seed 1), fp32, data resident in HBM.
+Workload (`config.workload`): BASELINE.json configs[2], the largest single-GPU configuration -- the full
+VAE-GAM (GP regressors, HRF on `task`, GLM least-squares regulariser on) on the synthetic checker-control
+set (2 subjects x 98 volumes of 41x49x35, 'Large3' control signal), 8 covariates incl. 6 motion,
+batch 64 PER GPU (weak scaling), random-init weights (seed 1), fp32, data resident in HBM.
+(`--batch 32 --covariates 3` runs configs[1].)
 A step = forward + backward + (N>1: RCCL all-reduce of the flat gradient buffer) + fused Adam on
-one minibatch.  `value` = N * 32 * K / t, t = max over ranks of the barrier-bracketed wall time.
+one minibatch.  `value` = N * batch * K / t, t = max over ranks of the barrier-bracketed wall time.
 
 roofline: the dominant kernel's ALGORITHMIC bytes (what it must read + write once, DESIGN.md
 "Kernels") / its mean duration, measured with HIP events recorded on the launching stream inside
-this run, against 8 TB/s.  cpu_baseline: the CPU oracle (oracle/vaegam_oracle.py, a "port" of the
-reference checked against reference goldens) timed on the host cores of this box on a bounded
-sample of the same workload, rank 0, N=1 only.
+this run, against 8 TB/s; `traffic` = the PMC-measured HBM bytes per launch of that kernel from the
+committed rocprofv3 passes (profiles/), emitted only while the kernel sources are byte-identical to
+the ones profiled (hash check), else null.
+cpu_baseline: the CPU oracle (oracle/vaegam_oracle.py, a "port" of the reference checked against
+reference goldens) timed on the host cores this process may use (count stated) on a bounded sample
+of the same workload, rank 0, N=1 only -- compute-only (`value`) and as-shipped-equivalent
+(`as_shipped_value`: + the per-forward image / figure logging and host copies the reference's
+forward performs in training, vae_reg_GP.py:331-337,370-372,381-398, emulated by oracle/as_shipped.py).
 """
 import argparse
 import json
@@ -32,15 +39,47 @@ ALG_GFLOP_PER_VOL = {3: 1.600, 8: 3.241, 12: 4.555}
 
 
 def host_threads():
-    """CPU threads this process may really use (cgroup quota / affinity), capped at the box's share."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    """(threads, note): every CPU this process may really use -- its affinity mask, cut to the cgroup CPU quota of the box
+    (threads beyond the quota only get throttled) -- and how that number came about, incl. the host's physical cores."""
+    n_aff = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    n, quota = n_aff, None
     try:
         q, p = open('/sys/fs/cgroup/cpu.max').read().split()
         if q != 'max':
-            n = min(n, max(1, int(float(q) / float(p))))
+            quota = float(q) / float(p)
+            n = min(n, max(1, int(quota)))
     except Exception:
         pass
-    return max(1, min(n, 16))
+    phys = None
+    try:
+        cores = set(); pid = cid = None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('physical id'):
+                pid = line.split(':')[1].strip()
+            elif line.startswith('core id'):
+                cid = line.split(':')[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    cores.add((pid, cid))
+                pid = cid = None
+        phys = len(cores) or None
+    except Exception:
+        pass
+    note = 'host: %s physical cores, %d logical CPUs in the affinity mask, cgroup cpu quota %s -> %d threads' % (
+        phys if phys else '?', n_aff, ('%.1f' % quota) if quota else 'none', max(1, n))
+    return max(1, n), note
+
+
+def kernel_source_sha():
+    """sha256 over the kernel sources + the C-ABI header: ties a committed PMC traffic figure to the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, 'vae-gam_amd', 'csrc')
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(('.hip', '.h')):
+            h.update(f.encode()); h.update(open(os.path.join(csrc, f), 'rb').read())
+    h.update(open(os.path.join(ROOT, 'include', 'vaegam.h'), 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def alg_bytes_per_launch(key, model, B):
@@ -61,7 +100,8 @@ def alg_bytes_per_launch(key, model, B):
         return None
     n_in = N * sp.ci * int(np.prod(sizes[i])); n_out = N * sp.co * int(np.prod(sizes[i + 1]))
     if fn in ('vg_corr3d', 'vg_tconv3d_s2', 'vg_tconv3d_s2_stats'):
-        extra = n_in if (direction == 'bwd') else 0          # bwd: + the saved activation read for the fused ReLU mask
+        has_mask = direction == 'bwd' and lname not in ('convt1', 'convt3', 'convt5', 'conv3', 'conv5')
+        extra = n_in if has_mask else 0                       # data gradient of a layer fed by a plain ReLU: + the saved activation (mask)
         return 4 * (n_in + n_out + extra)
     if fn == 'vg_wgrad3d':
         return 4 * (n_in + n_out)
@@ -73,11 +113,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32, help='minibatch per GPU')
-    ap.add_argument('--covariates', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=64, help='minibatch per GPU (configs[2]: 64; configs[1]: 32)')
+    ap.add_argument('--covariates', type=int, default=8, help='configs[2]: 8 (full model); configs[1]: 3')
     ap.add_argument('--subjects', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=5)
+    ap.add_argument('--cpu-steps', type=int, default=2, help='timed CPU-oracle steps (after 1 warm-up); ~7 s each at batch 64 / 8 covariates on 16 threads')
     ap.add_argument('--eager', action='store_true', help='launch kernels eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel HIP-event table to stderr')
     a = ap.parse_args()
@@ -158,9 +198,14 @@ def main():
         rows.append((tot, key, len(evs)))
     rows.sort(reverse=True)
     roofline = None
-    traffic_tab = {}
-    try:        # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, tools/profile_summary.py)
-        traffic_tab = json.load(open(os.path.join(ROOT, 'profiles', 'round1_traffic_by_layer.json')))
+    # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, tools/profile_summary.py): used only while the
+    # kernel sources hash to what was profiled and the workload is the profiled one -- a stale figure is dropped, not shown
+    traffic_tab, traffic_ok = {}, False
+    try:
+        cands = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_traffic_by_layer.json'))
+        traffic_tab = json.load(open(os.path.join(ROOT, 'profiles', cands[-1])))
+        meta = traffic_tab.get('_meta', {})
+        traffic_ok = (meta.get('kernel_source_sha') == kernel_source_sha() and meta.get('batch') == B and meta.get('covariates') == C)
     except Exception:
         pass
     for tot, key, n in rows:
@@ -171,7 +216,7 @@ def main():
         ach = ab / (per * 1e-3) / 1e9
         roofline = {'bound': 'hbm', 'kernel': key, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(ach / HBM_PEAK_GBS, 4),
-                    'traffic': (traffic_tab.get(key) or {}).get('hbm_bytes_per_launch') if (B == 32 and C == 3) else None,
+                    'traffic': (traffic_tab.get(key) or {}).get('hbm_bytes_per_launch') if traffic_ok else None,
                     'alg_bytes_per_launch': ab,
                     'avg_launch_us': round(per * 1e3, 2), 'launches': n,
                     'share_of_kernel_time': round(tot / max(sum(r[0] for r in rows), 1e-9), 3)}
@@ -188,7 +233,9 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, 'oracle'))
         import bridge
         import vaegam_oracle as O
-        nthr = host_threads()
+        import as_shipped
+        nthr, thr_note = host_threads()
+        print('[cpu_baseline] ' + thr_note, file=sys.stderr)
         torch.set_num_threads(nthr)
         cfg = bridge.oracle_config(model, glm_cdist=True)            # torch.cdist as the reference (vae_reg_GP.py:388)
         params = bridge.params_from_model(model)
@@ -197,26 +244,33 @@ def main():
         smp = batches[0]
         xc, cc = smp['volume'].cpu(), smp['covariates'].cpu()
         gen = torch.Generator().manual_seed(0)
-        for _ in range(2):                                                                # warm-ups (>= 5 timed steps after 2)
-            O.train_step(params, opt, cfg, xc, cc, glm, O.draw_noise(B, cfg, gen))
-        ts = []
-        for _ in range(a.cpu_steps):
+        O.train_step(params, opt, cfg, xc, cc, glm, O.draw_noise(B, cfg, gen))          # warm-up
+        ts, out_last = [], None
+        for _ in range(max(1, a.cpu_steps)):
             t1 = time.perf_counter()
-            O.train_step(params, opt, cfg, xc, cc, glm, O.draw_noise(B, cfg, gen))
+            out_last, _g = O.train_step(params, opt, cfg, xc, cc, glm, O.draw_noise(B, cfg, gen))
             ts.append(time.perf_counter() - t1)
         med = sorted(ts)[len(ts) // 2]
+        # as-shipped-equivalent: the reference's forward, in training, also copies (C+2) maps of B x V floats to host arrays and
+        # logs 9 x B image slices + C gain figures per call; that host work is timed once on this step's own outputs
+        t_log = as_shipped.time_forward_logging(out_last, cc, cfg)
         cpu = {'value': round(B / med, 2), 'unit': 'volumes/s', 'cores': nthr, 'kind': 'port',
-               'sample': '%d train steps of batch %d after 2 warm-ups (same synthetic minibatch, logging off), median; PyTorch CPU fp32'
-                         % (a.cpu_steps, B)}
+               'as_shipped_value': round(B / (med + t_log), 2),
+               'sample': '%d train step(s) of batch %d, %d covariates after 1 warm-up (same synthetic minibatch), median, PyTorch CPU '
+                         'fp32, compute only; as_shipped_value adds the %.2f s of per-forward logging + host copies the reference '
+                         'performs in training (emulated once on the same outputs); %s' % (len(ts), B, C, t_log, thr_note)}
 
     if rank == 0:
         out = {
             'metric': 'fMRI volumes/sec/train-step (41x49x35)', 'value': round(value, 1), 'unit': 'volumes/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': ('BASELINE configs[1]' if (B, C) == (32, 3) else 'BASELINE configs[2]' if (B, C) == (64, 8) else 'custom') + ': synthetic checker control (Large3), %d subjects x 98 volumes '
-                                   '41x49x35, %d covariates, batch %d per GPU, full train step (fwd+bwd+Adam), '
-                                   'gain/GP algebra on device in fp64, %s' % (a.subjects, C, B, 'hipGraph replay' if graphed else 'eager launches'),
+            'config': {'workload': ('configs[1]' if (B, C) == (32, 3) else 'configs[2] full VAE-GAM' if (B, C) == (64, 8) else 'custom') +
+                                   ': B=%d/GPU C=%d, 41x49x35, %d subj x 98 vol synthetic checker, fwd+bwd+Adam, %s'
+                                   % (B, C, a.subjects, 'hipGraph replay' if graphed else 'eager launches'),
+                       'detail': 'BASELINE.json configs[%s]: synthetic checker control (Large3 glyph, block design), GP regressors on the '
+                                 'continuous covariates, HRF on task, GLM regulariser on; gain / GP algebra on device in fp64'
+                                 % ('2' if (B, C) == (64, 8) else '1' if (B, C) == (32, 3) else '-'),
                        'global_batch': B * world, 'covariates': C, 'parallelism': 'dp%d' % world},
             'roofline': roofline,
             'step_roofline': {'hbm_frac': round(value / world * ALG_BYTES_PER_VOL.get(C, 0) / (HBM_PEAK_GBS * 1e9), 4),

@@ -355,5 +355,7 @@ def test_bench_emits_the_contract_line():
     assert out['value'] > 1000 and 'workload' in out['config'] and 'hipGraph replay' in out['config']['workload']
     rf = out['roofline']
     assert rf['bound'] == 'hbm' and rf['peak'] == 8000.0 and 0 < rf['frac'] < 1 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-3
+    assert out['config']['workload'].startswith('configs[2]') and out['config']['global_batch'] == 64 and out['config']['covariates'] == 8
     cb = out['cpu_baseline']
-    assert cb['kind'] == 'port' and cb['value'] > 0 and 1 <= cb['cores'] <= 16
+    assert cb['kind'] == 'port' and cb['value'] > 0 and cb['cores'] >= 1 and 0 < cb['as_shipped_value'] <= cb['value']
+    assert 'physical cores' in cb['sample']
