@@ -286,3 +286,48 @@ def test_jsonl_scalar_log(small_ds, tmp_path):
     cwd_before = set(os.listdir('.'))
     VAE(num_covariates=3, glm_maps=small_ds['glm'], xu_ranges=small_ds['xu_ranges'], device_name='cpu')
     assert set(os.listdir('.')) == cwd_before
+
+
+def test_sharded_batch_sampler_ranks_take_disjoint_slices_of_the_single_process_batches():
+    """dp.ShardedBatchSampler (the CLI's data-parallel loaders): per epoch every rank holds the contiguous slice of each global
+    minibatch, slices are disjoint, their union in rank order IS the minibatch one process would draw, all ranks take the same
+    number of equal-sized steps, and the order changes from epoch to epoch but is identical across ranks."""
+    from vae_gam_amd.dp import ShardedBatchSampler
+    n, gb, seed = 23, 8, 5
+    one = ShardedBatchSampler(n, gb, 0, 1, True, seed)
+    for world in (2, 4):
+        ranks = [ShardedBatchSampler(n, gb, r, world, True, seed) for r in range(world)]
+        one.set_epoch(0)
+        for epoch in range(3):
+            ref = list(iter(one))
+            per_rank = [list(iter(s_)) for s_ in ranks]
+            assert len({len(b) for b in per_rank}) == 1 and len(per_rank[0]) == len(ranks[0])
+            for k, batch in enumerate(zip(*per_rank)):
+                sizes = {len(x) for x in batch}
+                assert len(sizes) == 1                                   # equal-sized batches: the collectives stay in step
+                union = [i for part in batch for i in part]
+                assert len(set(union)) == len(union)                     # disjoint
+                assert union == ref[k][:len(union)]                      # rank order == the single-process minibatch
+                assert len(ref[k]) - len(union) < world                  # only the short last batch loses < world samples
+        assert list(iter(ShardedBatchSampler(n, gb, 0, 2, True, seed))) != list(iter(ShardedBatchSampler(n, gb, 0, 2, True, seed + 1)))
+    a = ShardedBatchSampler(n, gb, 1, 2, True, seed)
+    e0, e1 = list(iter(a)), list(iter(a))
+    assert e0 != e1                                                      # a new permutation every epoch
+    a.set_epoch(0)
+    assert list(iter(a)) == e0
+    u = ShardedBatchSampler(10, 4, 1, 2, False)
+    assert list(iter(u)) == [[2, 3], [6, 7], [9]]                        # unshuffled: identity order, same slicing
+
+
+def test_shard_loaders_rebuilds_every_loader_on_its_dataset(small_ds, tmp_path):
+    import types
+    from vae_gam_amd import DataClass_GP, dp as dpmod, synthetic
+    csv, _ = synthetic.write_csvs(small_ds, str(tmp_path))
+    loaders = DataClass_GP.setup_data_loaders(batch_size=2, train_csv=csv, test_csv=csv)
+    ctx = types.SimpleNamespace(rank=1, world_size=2)
+    out = dpmod.DataParallelContext.shard_loaders(ctx, loaders, 4, 1)
+    assert set(out) == {'Shuffled_train', 'UnShuffled_train', 'test'}
+    for k in out:
+        assert out[k].dataset is loaders[k].dataset
+    b = next(iter(out['UnShuffled_train']))
+    assert b['volume'].shape[0] == 2 and [int(v) for v in b['vol_num']] == [2, 3]      # rows 2,3 of the first global batch of 4

@@ -337,6 +337,80 @@ def test_reconstruct_writes_reference_layout_and_averages(tmp_path):
     np.testing.assert_allclose(avg['base'], np.mean(per_subj, axis=0), rtol=1e-5, atol=1e-6)
 
 
+def _cli_files(root, epoch):
+    e = str(epoch).zfill(3)
+    gp_dir = os.path.join(root, e + '_GP_plots')
+    rec = os.path.join(root, 'reconstructions', e + '_model_recons')
+    avg = os.path.join(root, 'reconstructions', e + '_avg_model_recons')
+    return gp_dir, rec, avg
+
+
+def test_cli_trains_then_exports_like_the_reference_wrapper(tmp_path):
+    """multsubj_reg_run_GP.main(argv) on a tiny synthetic CSV (the loaders carry the reference's 8 covariate columns): trains,
+    writes the checkpoint, then runs the reference's post-training block (multsubj_reg_run_GP.py:83-86): GP posterior CSVs,
+    per-volume reconstructions, subject / grand averages incl. the motion maps.  --recons_only --from_ckpt reproduces the
+    export from the checkpoint (:88-92) without training."""
+    from vae_gam_amd import multsubj_reg_run_GP as cli, synthetic
+    ds = synthetic.make_dataset(num_subjects=2, vols_per_subject=6, num_covariates=8, seed=3)
+    csv, glm_csv = synthetic.write_csvs(ds, str(tmp_path / 'data'))
+    out1 = str(tmp_path / 'run1')
+    m = cli.main(['--train_csv', csv, '--test_csv', csv, '--glm_maps', glm_csv, '--save_dir', out1, '--batch-size', '4',
+                  '--epochs', '2', '--save_freq', '1', '--test_freq', '1'])
+    assert m.epoch == 2 and os.path.exists(os.path.join(out1, 'checkpoint_001.tar'))
+    gp_dir, rec, avg = _cli_files(out1, 2)
+    assert sorted(os.listdir(gp_dir)) == sorted('002_GP_%s_full.csv' % n for n in ['x', 'y', 'z', 'xrot', 'yrot', 'zrot'])
+    subj = sorted(os.listdir(rec))
+    assert subj == ['subj00', 'subj01'] and len(os.listdir(os.path.join(rec, subj[0]))) == 6
+    assert len(os.listdir(os.path.join(rec, subj[0], 'vol_0'))) == 10
+    avg_files = [f for f in os.listdir(avg) if f.endswith('.nii')]
+    assert sorted(avg_files) == sorted('%s_avg.nii' % k for k in ['base', 'task', 'full_rec', 'x_mot', 'y_mot', 'z_mot', 'pitch_mot', 'roll_mot', 'yaw_mot', 'sex'])
+    out2 = str(tmp_path / 'run2')
+    m2 = cli.main(['--train_csv', csv, '--test_csv', csv, '--glm_maps', glm_csv, '--save_dir', out2, '--batch-size', '4',
+                   '--from_ckpt', 'True', '--ckpt_path', os.path.join(out1, 'checkpoint_001.tar'), '--recons_only', 'True'])
+    assert m2.epoch == 2 and m2.optimizer.step_count == 6
+    gp2, rec2, avg2 = _cli_files(out2, 2)
+    import pandas as pd
+    a = pd.read_csv(os.path.join(gp_dir, '002_GP_x_full.csv')); b = pd.read_csv(os.path.join(gp2, '002_GP_x_full.csv'))
+    np.testing.assert_allclose(a['mean'].to_numpy(), b['mean'].to_numpy(), rtol=1e-6, atol=1e-7)
+    assert len(os.listdir(os.path.join(rec2, 'subj01'))) == 6 and len(os.listdir(avg2)) >= 10
+
+
+def _cli_rank(rank, world, port, argv, out_file):
+    import os
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', VG_DP_BACKEND='gloo', VG_DP_FORCE='1')
+    from vae_gam_amd import multsubj_reg_run_GP as cli
+    m = cli.main(argv)
+    if rank == 0:
+        torch.save({'loss': m.loss, 'p': m.optimizer.groups[torch.float32]['p'].cpu()}, out_file)
+    m.dp.shutdown()
+
+
+def test_cli_two_ranks_train_on_disjoint_halves_of_the_global_batches(tmp_path):
+    """The CLI under torch.distributed (2 ranks sharing this box's GPU, gloo): --batch-size is the global minibatch, every rank
+    draws its own slice (dp.ShardedBatchSampler).  Epoch losses equal a 1-rank run of the same global batches with the same
+    seeded noise; ranks fed the SAME samples (round 1's pass-through shard_loaders) give different losses."""
+    import socket
+    import torch.multiprocessing as mp
+    from vae_gam_amd import synthetic
+    ds = synthetic.make_dataset(num_subjects=2, vols_per_subject=6, num_covariates=8, seed=3)
+    csv, glm_csv = synthetic.write_csvs(ds, str(tmp_path / 'data'))
+    res = {}
+    for world in (1, 2):
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        out_file = str(tmp_path / ('w%d.pt' % world))
+        argv = ['--train_csv', csv, '--test_csv', csv, '--glm_maps', glm_csv, '--save_dir', str(tmp_path / ('run_w%d' % world)),
+                '--batch-size', '4', '--epochs', '2', '--save_freq', '100', '--test_freq', '1']
+        mp.spawn(_cli_rank, args=(world, port, argv, out_file), nprocs=world, join=True)
+        res[world] = torch.load(out_file, weights_only=False)
+    for kind in ('train', 'test'):
+        for e, v in res[1]['loss'][kind].items():
+            np.testing.assert_allclose(res[2]['loss'][kind][e], v, rtol=2e-4, err_msg='%s epoch %d' % (kind, e))
+    dp_, p1 = res[2]['p'] - res[1]['p'], res[1]['p']
+    assert float(dp_.abs().max()) <= 4e-3                       # 6 Adam steps of lr 1e-3: same trajectory up to fp32 reduction order
+    assert os.path.isdir(_cli_files(str(tmp_path / 'run_w2'), 2)[1])     # rank 0 ran the export
+
+
 def test_bench_emits_the_contract_line():
     """bench.py (the driver's entry point): ONE JSON line on stdout with the metric, the roofline object of the dominant
     kernel (HIP events on the launch stream) and the CPU baseline timed in the same run."""

@@ -93,11 +93,64 @@ class DataParallelContext:
         return self.allreduce_sum_(t.clone())
 
     def shard_loaders(self, loaders, global_batch, seed):
-        return loaders            # file-backed loaders: every rank reads its own per-rank batch (see CLI)
+        """The DataLoaders of DataClass_GP.setup_data_loaders re-built so that every rank draws ITS slice of every global
+        minibatch: same data sets, `ShardedBatchSampler` instead of the per-process shuffling (which, seeded identically on
+        every rank, would hand all ranks the same samples)."""
+        from torch.utils.data import DataLoader
+        out = {}
+        for name, ld in loaders.items():
+            sampler = ShardedBatchSampler(len(ld.dataset), global_batch, self.rank, self.world_size,
+                                          shuffle=(name == 'Shuffled_train'), seed=seed)
+            out[name] = DataLoader(ld.dataset, batch_sampler=sampler, num_workers=0, collate_fn=ld.collate_fn)
+        return out
 
     def shutdown(self):
         if dist.is_initialized():
             dist.destroy_process_group()
+
+
+class ShardedBatchSampler:
+    """batch_sampler for torch's DataLoader under data parallelism (the reference has one process, DataClass_GP.py:73-89).
+
+    Every rank builds the SAME order of the data set for epoch e -- a permutation seeded with (seed, e) when shuffling, the
+    identity otherwise --, cuts it into global minibatches of `global_batch` indices and keeps the contiguous slice
+    [rank*b, (rank+1)*b) of each, b = global_batch / world: the ranks' slices are disjoint and their union, in rank order,
+    is the minibatch a single process would have drawn (the layout DeviceResidentData and forward_core's all-gather assume).
+    The last, short minibatch (the reference keeps it, drop_last=False) is cut to a multiple of the world size so that all
+    ranks take the same number of steps with equal-sized batches -- the collectives inside a step would otherwise deadlock;
+    at most world-1 samples per epoch are left out.  The epoch advances by itself on every __iter__ (one pass = one epoch on
+    every rank); set_epoch() pins it."""
+
+    def __init__(self, n, global_batch, rank, world, shuffle, seed=0):
+        if global_batch % world:
+            raise ValueError('global batch %d is not a multiple of the world size %d' % (global_batch, world))
+        self.n, self.global_batch, self.rank, self.world, self.shuffle, self.seed = int(n), int(global_batch), rank, world, shuffle, int(seed)
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def _batches(self, epoch):
+        if self.shuffle:
+            g = torch.Generator(); g.manual_seed(self.seed * 1000003 + epoch)
+            order = torch.randperm(self.n, generator=g).tolist()
+        else:
+            order = list(range(self.n))
+        for s in range(0, self.n, self.global_batch):
+            glob = order[s:s + self.global_batch]
+            b = len(glob) // self.world
+            if b == 0:
+                return
+            yield glob[self.rank * b:(self.rank + 1) * b]
+
+    def __iter__(self):
+        e = self.epoch
+        self.epoch += 1
+        return self._batches(e)
+
+    def __len__(self):
+        full, rest = divmod(self.n, self.global_batch)
+        return full + (1 if rest // self.world > 0 else 0)
 
 
 class _BnSync:

@@ -1,10 +1,15 @@
 """Command-line wrapper to train the VAE-GAM on MI355X (same flags as the reference's
 multsubj_reg_run_GP.py:19-56; run as `python -m vae_gam_amd.multsubj_reg_run_GP ...`).
 
-The post-hoc latent-UMAP / GP-plot / NIfTI reconstruction calls of the reference wrapper
-(multsubj_reg_run_GP.py:83-92) are outside the hot path; `--recons_only` therefore only loads the
-checkpoint and reports the test loss.  Multi-GPU: launch with torch.distributed.run, one process
-per GPU; the wrapper picks up RANK / LOCAL_RANK / WORLD_SIZE and shards each minibatch.
+After training -- or straight from a checkpoint with `--recons_only` -- the wrapper runs the reference's export pipeline
+(multsubj_reg_run_GP.py:79-92): `model.plot_GPs` (per-covariate GP posterior CSVs), `recon.mk_single_volumes` (one NIfTI
+per volume and map) and `recon.mk_avg_maps(mk_motion_maps=True)` (subject and grand averages), all on the training set as
+the reference does.  `project_latent` (a UMAP scatter plot of the latent means; umap-learn / plotting) is not part of the
+hot path and is skipped with a printed note.
+
+Multi-GPU: launch with torch.distributed.run, one process per GPU; the wrapper picks up RANK / LOCAL_RANK / WORLD_SIZE,
+`--batch-size` stays the GLOBAL minibatch and every rank draws its own slice of it (dp.ShardedBatchSampler); checkpoints
+and the export pipeline run on rank 0 only.
 """
 import argparse
 import os
@@ -49,13 +54,17 @@ def main(argv=None):
         os.makedirs(args.save_dir, exist_ok=True)
     main_start = time.time()
     dp = None
-    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 or os.environ.get('VG_DP_FORCE') == '1':
         from . import dp as dpmod
         dp = dpmod.DataParallelContext.from_env()
-    per_rank = args.batch_size if dp is None else args.batch_size // dp.world_size
-    loaders_dict = data.setup_data_loaders(batch_size=per_rank, train_csv=args.train_csv, test_csv=args.test_csv)
-    if dp is not None:
-        loaders_dict = dp.shard_loaders(loaders_dict, args.batch_size, args.seed)
+    rank = 0 if dp is None else dp.rank
+    if dp is not None and args.batch_size % dp.world_size:
+        raise SystemExit('--batch-size %d (the GLOBAL minibatch) must be a multiple of the %d ranks' % (args.batch_size, dp.world_size))
+    # the reference's loaders (whole data set, global minibatch): what the export pipeline iterates; under data parallelism the
+    # train / test loops get re-built loaders that hand each rank its slice of every global minibatch
+    full_loaders = data.setup_data_loaders(batch_size=args.batch_size if dp is None else args.batch_size // dp.world_size,
+                                           train_csv=args.train_csv, test_csv=args.test_csv)
+    loaders_dict = full_loaders if dp is None else dp.shard_loaders(full_loaders, args.batch_size, args.seed)
     model = vae_reg.VAE(num_inducing_pts=args.num_inducing_pts, gp_kl_scale=args.gp_kl_scale,
                         glm_reg_scale=args.glm_reg_scale, glm_maps=args.glm_maps, save_dir=args.save_dir,
                         csv_files=[args.train_csv, args.test_csv], neural_covariates=args.neural_covariates,
@@ -70,9 +79,30 @@ def main(argv=None):
                          save_dir=args.save_dir)
     else:
         assert args.from_ckpt, 'To choose recons_only option, --from_ckpt needs to be TRUE.'
-        model.test_epoch(loaders_dict['test'])
-    print('Total model runtime (seconds): {}'.format(time.time() - main_start))
+    export_outputs(model, full_loaders, args, dp)
+    if rank == 0:
+        print('Total model runtime (seconds): {}'.format(time.time() - main_start))
     return model
+
+
+def export_outputs(model, loaders_dict, args, dp=None):
+    """The post-training block of the reference wrapper (multsubj_reg_run_GP.py:83-86 and, for --recons_only, :89-92), on
+    the training set.  Rank 0 only under data parallelism: the replicas are identical, and the export runs single-process
+    (model.dp detached for its duration) while the other ranks wait at a barrier."""
+    from . import build_model_recons as recon
+    if dp is not None:
+        dp.barrier()
+    if dp is None or dp.rank == 0:
+        saved_dp, model.dp = model.dp, None
+        try:
+            print('project_latent (UMAP plot of the latent space, vae_reg_GP.py:542-583) is not part of this build: skipped.')
+            model.plot_GPs(csv_file=args.train_csv, save_dir=args.save_dir)
+            recon.mk_single_volumes(loaders_dict['UnShuffled_train'], model, args.train_csv, args.save_dir)
+            recon.mk_avg_maps(args.train_csv, model, args.save_dir, mk_motion_maps=True)
+        finally:
+            model.dp = saved_dp
+    if dp is not None:
+        dp.barrier()
 
 
 if __name__ == "__main__":

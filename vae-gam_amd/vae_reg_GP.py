@@ -438,7 +438,7 @@ class VAE(nn.Module):
         B, C, L = x.shape[0], self.num_covariates, self.num_latents
         dev = x.device
         x = x.float()
-        covariates = covariates.float()
+        covariates = covariates[:, :C].float()           # the loaders always carry the reference's 8 columns; covariate i reads column i-1 (:345)
         self._require_gpu(x)                         # before ANY launch: host pointers must never reach a kernel
         self._packed.refresh()                       # one launch: every conv weight -> the images the kernels read
         # data parallel: this rank holds rows [lo, lo+B) of a global batch of Bg = world*B volumes
@@ -617,6 +617,8 @@ class VAE(nn.Module):
             for i, sample in enumerate(test_loader):
                 ids, covariates, x = self._batch_to_device(sample)
                 total += self.forward(ids, covariates, x, 'test', train_mode=False).sum().double()
+        if self.dp is not None:
+            total = self.dp.sum_scalar_tensor(total)           # per-rank partials of the global-batch losses
         test_loss = float(total.item()) / len(test_loader.dataset)
         print('Test loss: {:.4f}'.format(test_loss))
         return test_loss
@@ -638,10 +640,10 @@ class VAE(nn.Module):
                 loss = self.test_epoch(loaders['test'])
                 self.loss['test'][epoch] = loss
                 self.writer.add_scalar("Loss/Test", loss, self.epoch)
-            if (save_freq is not None) and (epoch % save_freq == 0) and (epoch > 0):
+            if (save_freq is not None) and (epoch % save_freq == 0) and (epoch > 0) and (self.dp is None or self.dp.rank == 0):
                 filename = "checkpoint_" + str(epoch).zfill(3) + '.tar'
                 file_path = os.path.join(save_dir, filename)
-                self.save_state(file_path)
+                self.save_state(file_path)                      # data parallel: replicas are identical, rank 0 writes
         self.writer.close()
 
     def _log_gain_scalars(self):
