@@ -153,7 +153,35 @@ def run_case(ref_vae, name, seed, B, C, out_dir, neural=True):
     x = torch.from_numpy(inp['x']); cov = torch.from_numpy(inp['covariates'])
     ids = torch.zeros(B, dtype=torch.int64)
     model.train()
-    loss, z, imgs = model.forward(ids, cov, x, 'train', return_latent_rec=True, train_mode=False)
+    # the gains the reference forms inside forward (vae_reg_GP.py:368-380) are not returned: record them where they pass through
+    # torch -- the MultivariateNormal it constructs (loc = beta_mean, rsample = the gain before the HRF) and the first operand of
+    # the einsum that scales the effect map (= the gain that is actually applied, after the HRF where it applies)
+    rec = {'beta_mean': [], 'pre_hrf': [], 'applied': []}
+    MVN = ref_vae.MultivariateNormal
+
+    class RecordingMVN(MVN):
+        def __init__(self, loc, covariance_matrix=None, **kw):
+            super().__init__(loc, covariance_matrix, **kw)
+            rec['beta_mean'].append(loc.detach().clone())
+
+        def rsample(self, sample_shape=torch.Size()):
+            t = super().rsample(sample_shape)
+            rec['pre_hrf'].append(t.detach().clone())
+            return t
+    real_einsum = torch.einsum
+
+    def recording_einsum(eq, *ops):
+        if eq == 'b,bx->bx':
+            rec['applied'].append(ops[0].detach().clone())
+        return real_einsum(eq, *ops)
+    ref_vae.MultivariateNormal = RecordingMVN
+    torch.einsum = recording_einsum
+    try:
+        loss, z, imgs = model.forward(ids, cov, x, 'train', return_latent_rec=True, train_mode=False)
+    finally:
+        ref_vae.MultivariateNormal = MVN
+        torch.einsum = real_einsum
+    assert len(rec['beta_mean']) == len(rec['pre_hrf']) == len(rec['applied']) == C
     draws = tape.draws
     assert len(draws) == 2 + C and draws[0].shape == (B, 1) and draws[1].shape == (B, 32)
     noise = {'eps_w': draws[0], 'eps_d': draws[1], 'eps_beta': torch.stack(draws[2:2 + C])}
@@ -162,6 +190,12 @@ def run_case(ref_vae, name, seed, B, C, out_dir, neural=True):
     grads = {k: (None if v.grad is None else v.grad.detach().clone()) for k, v in name_map.items()
              if isinstance(v, torch.nn.Parameter)}
     mu, u, d = [t.detach() for t in model.encode(x)]
+
+    # float64 evaluation of the same step by the oracle restatement (pinned by tests/test_oracle_golden.py): the yardstick for
+    # quantities where the reference's own fp32 arithmetic is conditioning-limited (GP hyper-parameter gradients)
+    glm_full = np.concatenate([np.arange(cfg.V)[:, None].astype(np.float64), inp['glm_df'].to_numpy()], 1)
+    p64, x64, c64, n64 = O.to_float64(p, x, cov, noise)
+    out64, g64 = O.loss_and_grads(p64, cfg, x64, c64, torch.from_numpy(glm_full), n64)
 
     # GP posteriors straight from the reference's gp.GP (gp.py:67-110)
     ref_gp = sys.modules['gp']
@@ -207,6 +241,13 @@ def run_case(ref_vae, name, seed, B, C, out_dir, neural=True):
     for k in imgs:
         if isinstance(imgs[k], np.ndarray):            # unused covariate slots stay {} (vae_reg_GP.py:308)
             arrays['map.' + k] = map_stats(imgs[k], vox)
+    arrays['beta_mean'] = torch.stack(rec['beta_mean']).numpy()            # (C, B)
+    arrays['task_var_pre_hrf'] = torch.stack(rec['pre_hrf']).numpy()       # (C, B) MultivariateNormal.rsample(), :369
+    arrays['task_var'] = torch.stack(rec['applied']).numpy()               # (C, B) the gain applied to the effect map, :380
+    arrays['loss64'] = out64['loss'].detach().numpy()
+    for k, g_ in g64.items():
+        if g_ is not None and k.startswith('gp.'):
+            arrays['grad64.%s' % k] = g_.detach().double().flatten().numpy()
     for cname, (fb, Sg, klv) in gp_out.items():
         arrays['gp.%s.f_bar' % cname], arrays['gp.%s.Sigma' % cname], arrays['gp.%s.kl' % cname] = fb, Sg, klv
     gidx = {}

@@ -27,7 +27,7 @@ from vae_gam_amd.vae_reg_GP import VAE  # noqa: E402
 
 
 def case_inputs(B=32, C=3, data_seed=3, noise_seed=5, model_seed=1, device='cpu'):
-    ds = synthetic.make_dataset(num_subjects=2, vols_per_subject=20, num_covariates=C, seed=data_seed)
+    ds = synthetic.make_dataset(num_subjects=2, vols_per_subject=max(20, B // 2), num_covariates=C, seed=data_seed)
     torch.manual_seed(model_seed)
     model = VAE(num_covariates=C, glm_maps=ds['glm'], xu_ranges=ds['xu_ranges'], device_name=device)
     x = torch.from_numpy(ds['volumes'][:B]); cov = torch.from_numpy(ds['covariates'][:B])
@@ -58,25 +58,30 @@ def sample_idx(name, n, k=512):
     return np.sort(r.choice(n, min(k, n), replace=False))
 
 
-def main():
-    torch.set_num_threads(os.cpu_count() or 1)
-    ds, model, cfg, x, cov, noise = case_inputs()
+def write_case(name, B, C):
+    """fp32 (= the reference's arithmetic) and float64 oracle outputs of one train step at batch B, C covariates."""
+    ds, model, cfg, x, cov, noise = case_inputs(B=B, C=C)
     params = bridge.params_from_model(model)
     glm = torch.from_numpy(ds['glm'])
     t = time.time()
     out32, g32 = O.loss_and_grads(params, cfg, x, cov, glm, noise)
-    print('fp32 oracle %.1fs' % (time.time() - t), flush=True)
+    print('%s fp32 oracle %.1fs' % (name, time.time() - t), flush=True)
     t = time.time()
     p64, x64, c64, n64 = O.to_float64(params, x, cov, noise)
     out64, g64 = O.loss_and_grads(p64, cfg, x64, c64, glm, n64)
-    print('fp64 oracle %.1fs' % (time.time() - t), flush=True)
+    print('%s fp64 oracle %.1fs' % (name, time.time() - t), flush=True)
     arr = {'loss32': out32['loss'].detach().numpy(), 'loss64': out64['loss'].detach().numpy(),
            'slp32': out32['sum_log_prob'].detach().numpy(), 'z32': out32['z'].detach().numpy(),
            'kl_z32': out32['kl_z'].detach().numpy(), 'gp_kl32': out32['gp_kl_loss'].detach().numpy(),
-           'glm_reg32': out32['glm_reg'].detach().numpy()}
+           'glm_reg32': out32['glm_reg'].detach().numpy(),
+           'slp64': out64['sum_log_prob'].detach().numpy(), 'gp_kl64': out64['gp_kl_loss'].detach().numpy(),
+           'glm_reg64': out64['glm_reg'].detach().numpy()}
     for c in cfg.schema:
         arr['task_var32.' + c.name] = out32['task_var'][c.name].detach().numpy()
         arr['task_var64.' + c.name] = out64['task_var'][c.name].detach().numpy()
+        if c.gp:
+            arr['f_bar64.' + c.name] = out64['f_bar'][c.name].detach().numpy()
+            arr['Sigma_diag64.' + c.name] = out64['Sigma'][c.name].detach().diagonal().numpy().copy()
     for k in g32:
         if g32[k] is None:
             continue
@@ -87,9 +92,20 @@ def main():
         arr['g.%s.idx' % k] = idx
         arr['g.%s.val64' % k] = a64[idx]
         arr['g.%s.val32' % k] = a32[idx]
-    out = os.path.join(ROOT, 'tests', 'golden', 'oracle_B32_C3.npz')
+    out = os.path.join(ROOT, 'tests', 'golden', name + '.npz')
     np.savez_compressed(out, **arr)
     print('wrote', out, os.path.getsize(out))
+
+
+def main():
+    torch.set_num_threads(os.cpu_count() or 1)
+    only = sys.argv[1:]
+    if not only or 'B32_C3' in only:
+        write_case('oracle_B32_C3', 32, 3)
+    if not only or 'B64_C8' in only:
+        write_case('oracle_B64_C8', 64, 8)          # BASELINE configs[2]: the headline workload of bench.py
+    if only and 'hires' not in only:
+        return
     # ---- hi-res geometry, fp32 oracle only
     glm, model, cfg, x, cov, noise = hires_inputs()
     params = bridge.params_from_model(model)

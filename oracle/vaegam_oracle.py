@@ -384,7 +384,7 @@ def forward(p: Dict[str, torch.Tensor], cfg: OracleConfig, x: torch.Tensor, cova
     maps = {'base': x_rec}
     gp_kl_loss = torch.zeros(1, dtype=dt)
     glm_reg = torch.zeros((), dtype=dt)
-    f_bars, Sigmas, task_vars, beta_means, beta_covs = {}, {}, {}, {}, {}
+    f_bars, Sigmas, task_vars, beta_means, beta_covs, gp_kls = {}, {}, {}, {}, {}, {}
     eyeB = torch.eye(B, dtype=dt)
     for i, cov in enumerate(cfg.schema, start=1):                        # :338
         diff = decode(p, cfg, onehot(i), reduce_fn)                      # :339-343
@@ -401,7 +401,8 @@ def forward(p: Dict[str, torch.Tensor], cfg: OracleConfig, x: torch.Tensor, cova
             f_bar, Sigma = gp_posterior(p[pre + 'xu'], kvar, ls, p[pre + 'qu_m'], p[pre + 'qu_S'], xq)
             beta_mean = beta_mean + f_bar                                # :363
             beta_cov = beta_cov + Sigma                                  # :364
-            gp_kl_loss = gp_kl_loss + gp_kl(p[pre + 'qu_m'], p[pre + 'qu_S'], cfg.num_inducing_pts)  # :366-367
+            gp_kls[cov.name] = gp_kl(p[pre + 'qu_m'], p[pre + 'qu_S'], cfg.num_inducing_pts)
+            gp_kl_loss = gp_kl_loss + gp_kls[cov.name]                   # :366-367
             f_bars[cov.name], Sigmas[cov.name] = f_bar, Sigma
         Lb = torch.linalg.cholesky(beta_cov + 1e-5 * eyeB)               # :368 (MVN ctor)
         task_var = beta_mean + Lb @ noise['eps_beta'][i - 1]             # :369 rsample
@@ -433,7 +434,7 @@ def forward(p: Dict[str, torch.Tensor], cfg: OracleConfig, x: torch.Tensor, cova
     loss = -elbo + cfg.gp_kl_scale * gp_kl_loss + cfg.glm_reg_scale * glm_reg      # :410, shape (1,)
     out.update(loss=loss, elbo_b=elbo_b, sum_log_prob=sum_log_prob, gp_kl_loss=gp_kl_loss, glm_reg=glm_reg,
                f_bar=f_bars, Sigma=Sigmas, task_var=task_vars, beta_mean=beta_means, beta_cov=beta_covs,
-               maps=maps)
+               gp_kl_terms=gp_kls, maps=maps)
     return out
 
 

@@ -57,6 +57,11 @@ def test_oracle_matches_reference(golden_dir, name):
         if c.gp:
             np.testing.assert_allclose(out['f_bar'][c.name].detach().numpy(), g['gp.%s.f_bar' % c.name], atol=1e-4)
             np.testing.assert_allclose(out['Sigma'][c.name].detach().numpy(), g['gp.%s.Sigma' % c.name], atol=1e-4)
+            np.testing.assert_allclose(out['gp_kl_terms'][c.name].detach().numpy(), g['gp.%s.kl' % c.name], rtol=1e-5)
+    # gains as the reference forms them inside forward (recorded where they pass through torch, gen_golden.py)
+    for i, c in enumerate(cfg.schema):
+        np.testing.assert_allclose(out['beta_mean'][c.name].detach().numpy(), g['beta_mean'][i], atol=1e-4, rtol=1e-5, err_msg=c.name)
+        np.testing.assert_allclose(out['task_var'][c.name].detach().numpy(), g['task_var'][i], atol=2e-4, rtol=1e-4, err_msg=c.name)
     # --- gradients: same None pattern, norms and sampled entries
     for k, gr in grads.items():
         if ('grad.%s.none' % k) in g:

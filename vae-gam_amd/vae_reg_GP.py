@@ -181,6 +181,7 @@ class VAE(nn.Module):
         self.use_hip_graph = False     # capture the train step into a hipGraph (bench / long runs)
         self.recon_sums = None         # per-subject map sums left by reconstruct() for build_model_recons.mk_avg_maps
         self._graphs = {}
+        self.last_gp_kl = None
 
     # ------------------------------------------------------------------ construction helpers
     _GAIN_PREFIXES = ('sa_', 'logstd_', 'qu_m_', 'qu_S_', 'logkvar_', 'logls_')
@@ -388,7 +389,9 @@ class VAE(nn.Module):
             sel = K['sel']
             beta_mean = beta_mean + sel @ f_bar                                             # :363
             beta_cov = beta_cov + (sel @ Sigma.reshape(len(gidx), -1)).reshape(C, B, B)     # :364
-            gp_kl_loss = gp_kl_loss + gp.kl_batched(qu_m, qu_S).sum()                       # :366-367
+            kls = gp.kl_batched(qu_m, qu_S)
+            self.last_gp_kl = kls.detach()                                                  # per-covariate KL terms (parity tests, logging)
+            gp_kl_loss = gp_kl_loss + kls.sum()                                             # :366-367
             post = (gn, f_bar, Sigma)
         L = ops.cholesky(beta_cov + 1e-5 * eye)                                             # :368
         task_var = beta_mean + (L @ eps_beta.to(f64).unsqueeze(-1)).squeeze(-1)             # :369
