@@ -172,6 +172,37 @@ int vg_pack_weights(const float* flat_params, float* packed, const int64_t* segs
  * and MultivariateNormal(qu_m, qu_S) (gp.py:51); unlike hipSOLVER's potrf it can be captured into a hipGraph. */
 int vg_cholesky_f64(const double* a, double* l, int32_t batch, int32_t n, void* stream);
 
+/* The gain block of one minibatch: for every covariate i the sparse-GP posterior over the minibatch's query points, the gain
+ * covariance, its B x B Cholesky factor, the reparameterised gain sample, the HRF along the batch axis and both KL terms
+ * (vae_reg_GP.py:345-378 with gp.py:41-110: gp.GP.evaluate_posterior -- kernel build {Knu, Knn, Ku}, Ku solve --,
+ * compute_GP_kl, calc_linW_KL, MultivariateNormal(beta_mean, beta_cov + 1e-5 I).rsample(), do_hrf_conv), forward and backward,
+ * one workgroup per covariate, float64 arithmetic on fp32 inputs.
+ *   table  [C][10] int64 (device): {is_gp, is_hrf, gp_index, off_sa, off_logstd, off_qu_m, off_qu_S, off_logkvar, off_log_ls, 0},
+ *          offsets = element offsets of that covariate's parameters inside `params` (the flat fp32 parameter buffer);
+ *   xu     [#gp][n] fp32 inducing grids (row gp_index);  covariates: element (b, i) at covariates[b*ld_cov + i], B rows (the GLOBAL
+ *          batch under data parallelism);  eps_beta [C][B] fp32 standard-normal draws;  hrf_taps [hrf_taps] float64;
+ *   ws     caller workspace of vg_gp_gain_ws_bytes(C, B, n) bytes: written by the forward call, read by the backward call.
+ * forward outputs: task_var [C][B] fp32 (the gains), gp_kl [1] fp32 (sum over covariates of kl_lin (+ kl_gp)); optional float64
+ *   copies for exports / tests (NULL = not wanted): beta_mean [C][B], beta_cov [C][B][B], f_bar [C][B], Sigma [C][B][B]
+ *   (f_bar / Sigma rows of non-GP covariates are left untouched).
+ * backward: given g_task_var [C][B] fp32 and g_gp_kl [1] fp32, ADDS d loss / d {sa, logstd, qu_m, qu_S, logkvar, log_ls} into
+ *   flat_grads (fp32, same offsets as params).  No gradient flows to the covariates or the inducing grids (gp.py:92-101 builds
+ *   the distances from Python floats). */
+typedef struct vg_gain_desc {
+    int32_t C, B, n;           /* covariates, minibatch, inducing points */
+    int32_t hrf_taps;          /* 15 (utils.hrf(np.arange(0, 20, 1.4))); 0 = no HRF covariate */
+    double jitter_b;           /* 1e-5 (vae_reg_GP.py:368) */
+    double jitter_ku;          /* 0 = the reference's plain inverse of Ku (gp.py:107); > 0: Ku + jitter I (unit-variance scale) */
+    double prior_var;          /* 10 (gp.py:47) */
+} vg_gain_desc;
+int64_t vg_gp_gain_ws_bytes(int32_t C, int32_t B, int32_t n);
+int vg_gp_gain_fwd(const vg_gain_desc* d, const int64_t* table, const float* params, const float* xu,
+                   const float* covariates, int64_t ld_cov, const float* eps_beta, const double* hrf_taps, void* ws,
+                   float* task_var, float* gp_kl, double* beta_mean, double* beta_cov, double* f_bar, double* Sigma, void* stream);
+int vg_gp_gain_bwd(const vg_gain_desc* d, const int64_t* table, const float* params, const float* xu,
+                   const float* covariates, int64_t ld_cov, const float* eps_beta, const double* hrf_taps, void* ws,
+                   const float* g_task_var, const float* g_gp_kl, float* flat_grads, void* stream);
+
 /* fused Adam (torch.optim.Adam defaults, vae_reg_GP.py:179,429) over one flat buffer:
  * p,g,m,v: n elements of fp32 (is_f64 = 0) or fp64 (is_f64 = 1).  step_size = lr/(1-b1^t),
  * bc2_sqrt = sqrt(1-b2^t) are read from device scalars step_scalars[0..1] so a captured graph can replay

@@ -18,7 +18,8 @@ def oracle_config(model, glm_cdist=False):
     return O.OracleConfig(num_covariates=model.num_covariates, num_latents=model.num_latents,
                           num_inducing_pts=model.inducing_pts, gp_kl_scale=float(model.gp_kl_scale),
                           glm_reg_scale=float(model.glm_reg_scale), neural_covariates=bool(model.neural_covariates),
-                          img=tuple(model.img_shape), nf=model.nf, lr=model.lr, glm_cdist=glm_cdist)
+                          img=tuple(model.img_shape), nf=model.nf, lr=model.lr, glm_cdist=glm_cdist,
+                          gp_jitter=float(getattr(model, 'gp_jitter', 0.0)))
 
 
 def params_from_model(model):

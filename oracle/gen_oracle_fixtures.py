@@ -36,8 +36,10 @@ def case_inputs(B=32, C=3, data_seed=3, noise_seed=5, model_seed=1, device='cpu'
     return ds, model, cfg, x, cov, noise
 
 
-def hires_inputs(B=2, C=12, img=(82, 98, 70), seed=9, noise_seed=6, model_seed=1, device='cpu'):
-    """BASELINE configs[4] geometry (82x98x70, 12 covariates; no reference counterpart) at a tiny batch."""
+def hires_inputs(B=2, C=12, img=(82, 98, 70), seed=9, noise_seed=6, model_seed=1, device='cpu', n_ind=6, gp_jitter=0.0):
+    """BASELINE configs[4] geometry (82x98x70, 12 covariates; no reference counterpart) at a tiny batch.
+    n_ind = 64 with gp_jitter > 0 is configs[4] as stated (64 inducing points): the reference's plain inverse of Ku is singular
+    there in any precision; the jittered Cholesky form is the build's documented remedy."""
     rng = np.random.Generator(np.random.PCG64(seed))
     V = int(np.prod(img))
     x = torch.from_numpy(np.clip(0.5 + 0.25 * rng.standard_normal((B,) + img), 0, 1).astype(np.float32))
@@ -47,7 +49,7 @@ def hires_inputs(B=2, C=12, img=(82, 98, 70), seed=9, noise_seed=6, model_seed=1
     glm = rng.uniform(size=(V, C)); glm = glm / glm.max(0, keepdims=True)
     glm = np.concatenate([np.arange(V, dtype=np.float64)[:, None], glm], 1)
     torch.manual_seed(model_seed)
-    model = VAE(num_covariates=C, glm_maps=glm, xu_ranges=xu, device_name=device, img_shape=img)
+    model = VAE(num_covariates=C, glm_maps=glm, xu_ranges=xu, device_name=device, img_shape=img, num_inducing_pts=n_ind, gp_jitter=gp_jitter)
     cfg = bridge.oracle_config(model)
     noise = O.draw_noise(B, cfg, torch.Generator().manual_seed(noise_seed))
     return glm, model, cfg, x, torch.from_numpy(cov), noise
@@ -104,6 +106,32 @@ def main():
         write_case('oracle_B32_C3', 32, 3)
     if not only or 'B64_C8' in only:
         write_case('oracle_B64_C8', 64, 8)          # BASELINE configs[2]: the headline workload of bench.py
+    if not only or 'hires_n64' in only:
+        # configs[4] as stated: 64 inducing points -- float64 oracle with the jittered Ku (the yardstick; fp32 too, for scale)
+        glm, model, cfg, x, cov, noise = hires_inputs(n_ind=64, gp_jitter=1e-4)
+        params = bridge.params_from_model(model)
+        t = time.time()
+        out32, g32 = O.loss_and_grads(params, cfg, x, cov, torch.from_numpy(glm), noise)
+        p64, x64, c64, n64 = O.to_float64(params, x, cov, noise)
+        out64, g64 = O.loss_and_grads(p64, cfg, x64, c64, torch.from_numpy(glm), n64)
+        print('hi-res n=64 fp32 + fp64 oracle %.1fs' % (time.time() - t), flush=True)
+        arr = {'loss32': out32['loss'].detach().numpy(), 'loss64': out64['loss'].detach().numpy(),
+               'slp64': out64['sum_log_prob'].detach().numpy(), 'z64': out64['z'].detach().numpy(),
+               'gp_kl64': out64['gp_kl_loss'].detach().numpy()}
+        for c in cfg.schema:
+            arr['task_var64.' + c.name] = out64['task_var'][c.name].detach().numpy()
+            arr['task_var32.' + c.name] = out32['task_var'][c.name].detach().numpy()
+            if c.gp:
+                arr['f_bar64.' + c.name] = out64['f_bar'][c.name].detach().numpy()
+                arr['Sigma64.' + c.name] = out64['Sigma'][c.name].detach().numpy()
+        for k in g64:
+            if g64[k] is None or not k.startswith('gp.'):
+                continue
+            arr['g64.' + k] = g64[k].flatten().numpy()
+            arr['g32.' + k] = g32[k].double().flatten().numpy()
+        out = os.path.join(ROOT, 'tests', 'golden', 'oracle_hires_B2_C12_n64.npz')
+        np.savez_compressed(out, **arr)
+        print('wrote', out, os.path.getsize(out))
     if only and 'hires' not in only:
         return
     # ---- hi-res geometry, fp32 oracle only

@@ -108,6 +108,7 @@ class OracleConfig:
     nf: int = 8
     lr: float = 1e-3
     glm_cdist: bool = True   # True: torch.cdist as vae_reg_GP.py:388; False: the closed form B*sum_b||.||
+    gp_jitter: float = 0.0   # 0: the reference's torch.inverse(Ku) (gp.py:107); > 0: Ku + jitter*k_var*I (SURVEY H2 remedy, no reference counterpart)
 
     @property
     def schema(self) -> List[Covariate]:
@@ -318,7 +319,7 @@ def gp_kernel(dist, k_var, ls, scale=1.0):
     return k_var * torch.exp(-torch.pow(scale / np.sqrt(2) / ls * dist, 2))
 
 
-def gp_posterior(xu: torch.Tensor, k_var, ls, qu_m, qu_S, xq: torch.Tensor):
+def gp_posterior(xu: torch.Tensor, k_var, ls, qu_m, qu_S, xq: torch.Tensor, jitter: float = 0.0):
     """gp.GP.evaluate_posterior (gp.py:67-110), vectorised.  The reference builds the
     inducing-to-query distances as arange(Xu0 - xq_j, ., step)[:n] with python floats
     (gp.py:92-94), i.e. (Xu0 - xq_j) + k*step with NO gradient to xq/Xu; Ku from the
@@ -331,6 +332,8 @@ def gp_posterior(xu: torch.Tensor, k_var, ls, qu_m, qu_S, xq: torch.Tensor):
     knn = gp_kernel(xq.unsqueeze(0) - xq.unsqueeze(1), k_var, ls)          # knn[i,:] = xq - xq[i]
     idx = torch.arange(n, dtype=xq.dtype)
     ku = gp_kernel((idx.unsqueeze(0) - idx.unsqueeze(1)).abs(), k_var, ls, step)
+    if jitter:                                                             # H2 remedy: inducing prior k_var (Ku1 + jitter I)
+        ku = ku + jitter * k_var * torch.eye(n, dtype=ku.dtype)
     A = knu.T @ torch.inverse(ku)
     f_bar = A @ torch.squeeze(qu_m)
     Sigma = knn + (A @ (qu_S - ku) @ A.T)
@@ -398,7 +401,7 @@ def forward(p: Dict[str, torch.Tensor], cfg: OracleConfig, x: torch.Tensor, cova
             pre = 'gp.%s.' % cov.name
             kvar = p[pre + 'logkvar'].exp() + 0.1                        # :355
             ls = 3.0 * torch.sigmoid(p[pre + 'log_ls'].exp() + 0.5)      # :357
-            f_bar, Sigma = gp_posterior(p[pre + 'xu'], kvar, ls, p[pre + 'qu_m'], p[pre + 'qu_S'], xq)
+            f_bar, Sigma = gp_posterior(p[pre + 'xu'], kvar, ls, p[pre + 'qu_m'], p[pre + 'qu_S'], xq, cfg.gp_jitter)
             beta_mean = beta_mean + f_bar                                # :363
             beta_cov = beta_cov + Sigma                                  # :364
             gp_kls[cov.name] = gp_kl(p[pre + 'qu_m'], p[pre + 'qu_S'], cfg.num_inducing_pts)

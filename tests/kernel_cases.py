@@ -260,3 +260,123 @@ def run_cholesky_case(dev, batch=3, n=32, seed=0):
     np.testing.assert_allclose(l.detach().cpu().numpy(), l_ref.detach().numpy(), rtol=1e-10, atol=1e-10)
     (ga,) = torch.autograd.grad((l * w.to(dev)).sum(), a_d)
     np.testing.assert_allclose(ga.cpu().numpy(), ga_ref.numpy(), rtol=1e-8, atol=1e-8)
+
+
+def run_gain_case(dev, B=12, n=6, jitter=0.0, seed=0, kinds=('lin_hrf', 'gp', 'gp', 'gp_hrf', 'lin')):
+    """vg_gp_gain_fwd / _bwd (one workgroup per covariate: GP posterior, gain covariance, B x B Cholesky, gain sample, HRF,
+    both KLs) against the float64 oracle restatement of vae_reg_GP.py:345-378 / gp.py:41-110 with autograd for the gradients."""
+    import math
+    import vaegam_oracle as O
+    g = torch.Generator().manual_seed(seed)
+    C = len(kinds)
+    P, table, xus, leaves = [], [], [], []
+
+    def put(t):
+        off = sum(x.numel() for x in P); P.append(t.reshape(-1).float()); return off
+    for kind in kinds:
+        sa, logstd = 1 + torch.randn(1, 1, generator=g), 0.3 * torch.randn(1, 1, generator=g)
+        row = [int(kind.startswith('gp')), int(kind.endswith('hrf')), len(xus), put(sa), put(logstd), 0, 0, 0, 0, 0]
+        lv = {'sa': sa, 'logstd': logstd}
+        if kind.startswith('gp'):
+            qm = torch.randn(1, n, generator=g)
+            r = 0.2 * torch.randn(n, n, generator=g)
+            qS = 2 * torch.eye(n) + r @ r.t()
+            lk, ll = 0.3 * torch.randn((), generator=g), 0.3 * torch.randn((), generator=g)
+            row[5], row[6], row[7], row[8] = put(qm), put(qS), put(lk), put(ll)
+            xus.append(torch.linspace(-4.1, 6.2, n))
+            lv.update(qu_m=qm, qu_S=qS, logkvar=lk, log_ls=ll, xu=xus[-1])
+        table.append(row); leaves.append(lv)
+    flat = torch.cat(P)
+    cov = torch.randn(B, C + 2, generator=g) * 1.5
+    cov[0, :] = 6.0; cov[1, :] = -4.0
+    eps = torch.randn(C, B, generator=g)
+    wt, wk = torch.randn(C, B, generator=g), 0.7
+    # ---- float64 reference with autograd
+    ref_leaves = []
+    tv_ref, kl_ref, fb_ref, sg_ref = [], 0.0, {}, {}
+    for i, (kind, lv) in enumerate(zip(kinds, leaves)):
+        q = {k: v.float().double().clone().requires_grad_(k != 'xu') for k, v in lv.items()}
+        ref_leaves.append(q)
+        xq = cov[:, i].double()
+        sa, std = q['sa'][0], q['logstd'][0].exp()
+        kl_ref = kl_ref + O.lin_gain_kl(sa, std)
+        bm = sa * xq
+        bc = std.pow(2) * xq.pow(2) * torch.eye(B, dtype=torch.float64)
+        if kind.startswith('gp'):
+            kvar = q['logkvar'].exp() + 0.1
+            ls = 3.0 * torch.sigmoid(q['log_ls'].exp() + 0.5)
+            fb, Sg = O.gp_posterior(q['xu'].float(), kvar, ls, q['qu_m'], q['qu_S'], xq, jitter)
+            if jitter:
+                # dense grid, cond(Ku) ~ n / jitter: autograd through the oracle's inverse(k_var Ku) makes d/d k_var a difference of
+                # huge cancelling terms (A does not depend on k_var at all).  Gradients are therefore taken through the same
+                # posterior written with A built from unit-variance kernels -- tied to the oracle by its forward values.
+                fb_o, Sg_o = fb.detach(), Sg.detach()
+                fb, Sg = _posterior_unit_variance(q['xu'].float(), kvar, ls, q['qu_m'], q['qu_S'], xq, jitter)
+                np.testing.assert_allclose(fb.detach().numpy(), fb_o.numpy(), atol=2e-5 * max(1.0, float(fb_o.abs().max())))
+                np.testing.assert_allclose(Sg.detach().numpy(), Sg_o.numpy(), atol=2e-5 * max(1.0, float(Sg_o.abs().max())))
+            bm = bm + fb; bc = bc + Sg
+            kl_ref = kl_ref + O.gp_kl(q['qu_m'], q['qu_S'], n)
+            fb_ref[i], sg_ref[i] = fb.detach(), Sg.detach()
+        L = torch.linalg.cholesky(bc + 1e-5 * torch.eye(B, dtype=torch.float64))
+        tv = bm + L @ eps[i].double()
+        if kind.endswith('hrf'):
+            tv = _hrf64(tv)
+        tv_ref.append(tv)
+    tv_ref = torch.stack(tv_ref)
+    loss_ref = (tv_ref * wt.double()).sum() + wk * kl_ref.sum()
+    loss_ref.backward()
+    # ---- the kernel
+    consts = ops.GainConsts(torch.tensor(table, dtype=torch.int64).to(dev), torch.stack(xus).float().to(dev),
+                            _hrf_taps().to(dev), n, jitter_ku=jitter)
+    fp = flat.to(dev).clone().requires_grad_(True)
+    fg = torch.zeros_like(fp)
+    tv, kl, bm_, bc_, fb_, sg_, klt = ops.GpGain.apply(cov.to(dev), eps.to(dev), consts, fp.detach(), fg, None, fp)
+    np.testing.assert_allclose(tv.detach().cpu().numpy(), tv_ref.detach().numpy(), rtol=2e-6, atol=2e-6 * float(tv_ref.abs().max()))
+    np.testing.assert_allclose(float(kl.detach()), float(kl_ref.sum()), rtol=1e-6)
+    # (the kernel rounds the inducing-to-query distances to fp32 as the reference's fp32 Knu does, gp.py:90; the float64 oracle
+    # does not: ~1e-7 relative on a distance, amplified by cond(Ku) ~ 1e2)
+    for i in fb_ref:
+        np.testing.assert_allclose(fb_[i].cpu().numpy(), fb_ref[i].numpy(), atol=2e-5)
+        np.testing.assert_allclose(sg_[i].cpu().numpy(), sg_ref[i].numpy(), atol=2e-5)
+    ((tv * wt.to(dev)).sum() + wk * kl.sum()).backward()
+    got = fg.cpu().double()
+    for i, (kind, q, row) in enumerate(zip(kinds, ref_leaves, table)):
+        names = ['sa', 'logstd'] + (['qu_m', 'qu_S', 'logkvar', 'log_ls'] if kind.startswith('gp') else [])
+        offs = {'sa': row[3], 'logstd': row[4], 'qu_m': row[5], 'qu_S': row[6], 'logkvar': row[7], 'log_ls': row[8]}
+        for nm in names:
+            want = q[nm].grad.reshape(-1)
+            have = got[offs[nm]:offs[nm] + want.numel()]
+            # d log_ls / d logkvar are cancelling sums: tiny values carry the fp32-distance noise
+            scale = max(float(want.abs().max()), 1e-2)
+            np.testing.assert_allclose(have.numpy(), want.numpy(), rtol=2e-4, atol=2e-4 * scale, err_msg='cov %d (%s) d%s' % (i, kind, nm))
+
+
+def _posterior_unit_variance(xu, k_var, ls, qu_m, qu_S, xq, jitter):
+    """oracle.gp_posterior (gp.py:67-110) with A = Knu^T Ku^-1 formed from UNIT-variance kernels (k_var cancels in A)."""
+    import vaegam_oracle as O
+    n = xu.shape[0]
+    step = (xu[1] - xu[0]).double()
+    knu_d = (xu[0].double() - xq).unsqueeze(0) + torch.arange(n, dtype=torch.float64).unsqueeze(1) * step
+    one = torch.ones((), dtype=torch.float64)
+    knu1 = O.gp_kernel(knu_d, one, ls)
+    knn1 = O.gp_kernel(xq.unsqueeze(0) - xq.unsqueeze(1), one, ls)
+    idx = torch.arange(n, dtype=torch.float64)
+    ku1 = O.gp_kernel((idx.unsqueeze(0) - idx.unsqueeze(1)).abs(), one, ls, step) + jitter * torch.eye(n, dtype=torch.float64)
+    A = knu1.T @ torch.inverse(ku1)
+    return A @ torch.squeeze(qu_m), k_var * knn1 + A @ (qu_S - k_var * ku1) @ A.T
+
+
+def _hrf_taps():
+    from vae_gam_amd import utils
+    return torch.tensor(utils.hrf(np.arange(0, 20, 1.4))).float().double()
+
+
+def _hrf64(tv):
+    """causal HRF along the batch index with the fp32-rounded taps, float64 accumulate (vae_reg_GP.py:283-305)"""
+    hk = _hrf_taps()
+    B = tv.shape[0]
+    T = torch.zeros(B, B, dtype=torch.float64)
+    for i in range(B):
+        m = min(hk.shape[0], B - i)
+        T[i, i:i + m] = hk[:m]
+    return tv @ T

@@ -78,3 +78,8 @@ def test_adam(dtype):
 @pytest.mark.parametrize('n', [6, 32, 64])
 def test_cholesky(n):
     K.run_cholesky_case('cpu', batch=3, n=n)
+
+
+@pytest.mark.parametrize('B,n,jitter', [(12, 6, 0.0), (17, 6, 0.0), (7, 12, 1e-5)])
+def test_gain_block_matches_float64_oracle(B, n, jitter):
+    K.run_gain_case('cpu', B=B, n=n, jitter=jitter, seed=B)

@@ -28,6 +28,10 @@ class WgradDesc(ctypes.Structure):
                                    'stride', 'pad_d', 'pad_h', 'pad_w', 'pro_on_a', 'relu_in', 'per_group')]
 
 
+class GainDesc(ctypes.Structure):
+    _fields_ = [('C', i32), ('B', i32), ('n', i32), ('hrf_taps', i32), ('jitter_b', f64), ('jitter_ku', f64), ('prior_var', f64)]
+
+
 _PROTOS = {
     'vg_version': (ctypes.c_int, []),
     'vg_last_error': (ctypes.c_char_p, []),
@@ -54,6 +58,9 @@ _PROTOS = {
     'vg_gam_elbo_bwd': (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, vp]),
     'vg_pack_weights': (ctypes.c_int, [vp, vp, vp, i32, i64, vp]),
     'vg_cholesky_f64': (ctypes.c_int, [vp, vp, i32, i32, vp]),
+    'vg_gp_gain_ws_bytes': (i64, [i32, i32, i32]),
+    'vg_gp_gain_fwd': (ctypes.c_int, [ctypes.POINTER(GainDesc), vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'vg_gp_gain_bwd': (ctypes.c_int, [ctypes.POINTER(GainDesc), vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]),
     'vg_adam_advance': (ctypes.c_int, [vp, f64, f64, f64, vp]),
     'vg_adam_step': (ctypes.c_int, [vp, vp, vp, vp, i64, i32, f64, f64, f64, vp, vp]),
 }

@@ -1,0 +1,514 @@
+// vg_gp.hip -- the per-covariate gain block of the VAE-GAM (gfx950): sparse variational GP posterior, gain covariance,
+// B x B Cholesky, reparameterised gain sample, HRF along the batch axis, both KL terms -- forward and hand-derived
+// backward, ONE workgroup per covariate, float64.
+//
+// Replaces, per covariate i (vae_reg_GP.py:345-378 with gp.py:41-110), what the reference does as two Python loops over the
+// minibatch with a float() host sync per query point, an fp32 torch.inverse, a MultivariateNormal constructor (Cholesky) and
+// an rsample -- and what round 1 of this build did as ~300 batched ATen launches:
+//   std = exp(logstd);  kl_lin = KL(N(sa, std^2) || N(1, 0.5^2))                                    (:266-281, :346-348)
+//   beta_mean = sa x,  beta_cov = diag(std^2 x^2)                                                   (:349-351)
+//   continuous covariates:  kvar = exp(logkvar) + 0.1,  ls = 3 sigmoid(exp(log_ls) + 0.5)           (:355-357)
+//       Knu[k][b] = k((Xu0 - x_b) + k step)  (distance rounded to fp32 as gp.py:90),  Knn[i][j] = k(x_j - x_i),
+//       Ku[a][b] = k(|a-b| step),  k(d) = exp(-(d / (sqrt2 ls))^2)  (unit variance: it cancels in A)  (gp.py:88-105, 121-136)
+//       A = Knu^T Ku^-1,  f = A m,  Sigma = kvar Knn + A (S - kvar Ku) A^T                          (gp.py:107-109)
+//       beta_mean += f,  beta_cov += Sigma,  kl_gp = KL(N(m, S) || N(0, 10 I)) via chol(S)          (:363-367, gp.py:41-65)
+//   L = chol(beta_cov + 1e-5 I),  gain = beta_mean + L eps                                          (:368-369)
+//   neural covariates:  gain <- causal 15-tap HRF convolution of gain along the BATCH index         (:283-305, :377-378)
+// Everything is evaluated in float64 (parameters, covariates and noise are fp32 values widened on load): the gain covariance
+// is within 1e-5 of singular and the reference's own fp32 gradients through this block are rounding noise.
+// Ku^-1 comes from a Cholesky factorisation of Ku + jitter_ku I (jitter_ku = 0 reproduces the reference's inverse; > 0 is the
+// remedy for dense inducing grids where Ku is singular in any precision).
+//
+// Memory: the B x B matrix lives in LDS while it fits (B <= 128), in the caller's workspace (L2-resident) beyond that, so the
+// data-parallel global batch (256, 512) runs through the same code.  Every other array (B x n, n x n, vectors) is in the
+// workspace.  Parameter gradients are ADDED straight into the flat fp32 gradient buffer at the parameters' own offsets.
+#include "vg_common.h"
+#include "../../include/vaegam.h"
+
+namespace {
+
+constexpr int GP_T = 256;                  // threads per workgroup
+constexpr int GP_LDS_MAXB = 128;           // B*B*8 <= 128 KiB of the 160 KiB LDS
+constexpr int TAB_W = 10;                  // table row: {is_gp, is_hrf, gp_index, off_sa, off_logstd, off_qu_m, off_qu_S, off_logkvar, off_log_ls, 0}
+
+struct GpLayout {                          // workspace of ONE covariate, in doubles
+    long long Lc, A, kinv, Ls, M, N1, N2, N3, N4, T1, T2, T3, G, x, e, bm, v1, v2, v3, sc, total;
+};
+
+__host__ __device__ inline GpLayout gp_layout(long long B, long long n) {
+    GpLayout w; long long o = 0;
+    w.Lc = o; o += B * B;                  // chol(beta_cov + jitter)            saved for the backward pass
+    w.A = o; o += B * n;                   // A = Knu^T Ku^-1                    saved
+    w.kinv = o; o += n * n;                // (Ku + jitter)^-1                   saved
+    w.Ls = o; o += n * n;                  // chol(S)                            saved
+    w.M = o; o += n * n;                   // S - kvar Ku
+    w.N1 = o; o += n * n; w.N2 = o; o += n * n; w.N3 = o; o += n * n; w.N4 = o; o += n * n;     // n x n scratch
+    w.T1 = o; o += B * n; w.T2 = o; o += B * n; w.T3 = o; o += B * n;
+    w.G = o; o += B * B;                   // backward: d loss / d beta_cov (when it does not fit LDS)
+    w.x = o; o += B; w.e = o; o += B; w.bm = o; o += B; w.v1 = o; o += B; w.v2 = o; o += B; w.v3 = o; o += B;
+    w.sc = o; o += 16;
+    w.total = (o + 7) / 8 * 8;
+    return w;
+}
+
+// ---- block-cooperative dense helpers (all threads of the workgroup call them; `m` may point to LDS or global memory)
+
+// in-place right-looking Cholesky of the lower triangle of m (n x n, row-major); the upper triangle is zeroed
+__device__ void chol_inplace(double* m, int n) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int j = 0; j < n; ++j) {
+        __syncthreads();
+        const double d = sqrt(m[j * n + j]);           // NaN for a non-positive pivot, as cholesky_ex(check_errors=False)
+        __syncthreads();
+        for (int i = j + tid; i < n; i += nt) m[i * n + j] = (i == j) ? d : m[i * n + j] / d;
+        __syncthreads();
+        const int r = n - j - 1;
+        for (long long t = tid; t < (long long)r * r; t += nt) {
+            const int i = j + 1 + (int)(t / r), k = j + 1 + (int)(t % r);
+            if (k <= i) m[i * n + k] -= m[i * n + j] * m[k * n + j];
+        }
+    }
+    __syncthreads();
+    for (long long t = tid; t < (long long)n * n; t += nt) { const int i = (int)(t / n), k = (int)(t % n); if (k > i) m[t] = 0.0; }
+    __syncthreads();
+}
+
+// X <- L^-T X in place (L lower triangular n x n, X n x nc row-major with leading dimension ldx): right-looking back substitution
+__device__ void solve_LT_inplace(const double* L, int n, double* X, int nc, int ldx) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = n - 1; i >= 0; --i) {
+        __syncthreads();
+        const double inv = 1.0 / L[i * n + i];
+        for (int c = tid; c < nc; c += nt) X[(long long)i * ldx + c] *= inv;
+        __syncthreads();
+        for (long long t = tid; t < (long long)i * nc; t += nt) {
+            const int r = (int)(t / nc), c = (int)(t % nc);
+            X[(long long)r * ldx + c] -= L[i * n + r] * X[(long long)i * ldx + c];
+        }
+    }
+    __syncthreads();
+}
+
+// inv <- (L L^T)^-1 for lower-triangular L (n x n); tmp: n x n scratch (receives L^-1)
+__device__ void spd_inverse_from_chol(const double* L, int n, double* tmp, double* inv) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    // column j of L^-1 by forward substitution (one thread per column; n <= a few dozen)
+    for (int j = tid; j < n; j += nt) {
+        for (int i = 0; i < n; ++i) {
+            double s = (i == j) ? 1.0 : 0.0;
+            for (int k = j; k < i; ++k) s -= L[i * n + k] * tmp[k * n + j];
+            tmp[i * n + j] = (i < j) ? 0.0 : s / L[i * n + i];
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < n * n; t += nt) {
+        const int a = t / n, b = t % n;
+        double s = 0.0;
+        for (int k = max(a, b); k < n; ++k) s += tmp[k * n + a] * tmp[k * n + b];
+        inv[t] = s;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ double kern1(double d, double inv_s2ls) { const double t = inv_s2ls * d; return exp(-(t * t)); }
+
+// inducing point k to query point x: (Xu0 - x) + k step.  The reference builds Knu in fp32 (gp.py:90), i.e. on distances rounded to
+// fp32; that rounding is reproduced in the bug-compatible mode (jitter_ku == 0, well-conditioned grids).  With the H2 remedy
+// switched on the grid is dense, cond(Ku) reaches 1e6..1e8 and a 1e-7 relative perturbation of a distance would move the
+// posterior by percents: the distance then stays in float64.
+__device__ __forceinline__ double knu_dist(double xu0, double xb, int k, double step, bool round32) {
+    const double d = (xu0 - xb) + (double)k * step;
+    return round32 ? (double)(float)d : d;
+}
+
+// block-wide sum of one double per thread (fixed order): red = GP_T doubles of LDS
+__device__ double block_sum(double v, double* red) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+    for (int s = GP_T / 2; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+struct GainArgs {
+    int C, B, n, taps;
+    double jitter_b, jitter_ku, prior_var;
+    const long long* tab; const float* P; const float* xu; const float* cov; long long ldc; const float* eps; const double* hrf;
+    double* ws;
+};
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ void __launch_bounds__(GP_T)
+gain_fwd_k(GainArgs a, float* __restrict__ task_var, double* __restrict__ kl_part,
+           double* __restrict__ o_bm, double* __restrict__ o_bc, double* __restrict__ o_fb, double* __restrict__ o_sg) {
+    VG_DYN_SMEM(double, lds);
+    double* red = lds;                                         // GP_T doubles
+    const int c = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int B = a.B, n = a.n;
+    const GpLayout w = gp_layout(B, n);
+    double* W = a.ws + (size_t)c * w.total;
+    const bool in_lds = B <= GP_LDS_MAXB;
+    double* Cm = in_lds ? lds + GP_T : W + w.Lc;               // the B x B matrix being built / factorised
+    const long long* tb = a.tab + (size_t)c * TAB_W;
+    const bool is_gp = tb[0] != 0, is_hrf = tb[1] != 0;
+    const int gk = (int)tb[2];
+    double* x = W + w.x; double* e = W + w.e; double* bm = W + w.bm;
+    const double sa = (double)a.P[tb[3]], std_ = exp((double)a.P[tb[4]]);
+    for (int b = tid; b < B; b += nt) {
+        const double xv = (double)a.cov[(size_t)b * a.ldc + c];
+        x[b] = xv; e[b] = (double)a.eps[(size_t)c * B + b]; bm[b] = sa * xv;
+    }
+    const double vr = (std_ / 0.5) * (std_ / 0.5), t1 = ((sa - 1.0) / 0.5) * ((sa - 1.0) / 0.5);
+    double kl = 0.5 * (vr + t1 - 1.0 - log(vr));               // calc_linW_KL
+    double kvar = 0.0, ls = 1.0, step = 0.0;
+    __syncthreads();
+    if (is_gp) {
+        const float* xu = a.xu + (size_t)gk * n;
+        const float stepf = xu[1] - xu[0];                     // fp32, as (xu[1] - xu[0]) of the reference
+        step = (double)stepf;
+        const double xu0 = (double)xu[0];
+        kvar = exp((double)a.P[tb[7]]) + 0.1;
+        ls = 3.0 / (1.0 + exp(-(exp((double)a.P[tb[8]]) + 0.5)));
+        const double isl = 1.0 / sqrt(2.0) / ls;
+        const float* qm = a.P + tb[5]; const float* qS = a.P + tb[6];
+        double* N1 = W + w.N1; double* N2 = W + w.N2; double* kinv = W + w.kinv; double* A = W + w.A; double* M = W + w.M;
+        double* T1 = W + w.T1; double* T2 = W + w.T2; double* Ls = W + w.Ls;
+        // Ku (+ jitter) -> Cholesky -> inverse
+        for (int t = tid; t < n * n; t += nt) {
+            const int p = t / n, q = t % n;
+            N1[t] = kern1(fabs((double)(p - q)) * step, isl) + (p == q ? a.jitter_ku : 0.0);
+        }
+        __syncthreads();
+        chol_inplace(N1, n);
+        spd_inverse_from_chol(N1, n, N2, kinv);
+        // Knu^T (B x n), distances rounded to fp32 as the reference builds them; A = Knu^T Ku^-1
+        for (int t = tid; t < B * n; t += nt) {
+            const int b = t / n, k = t % n;
+            T1[t] = kern1(knu_dist(xu0, x[b], k, step, a.jitter_ku == 0.0), isl);
+        }
+        __syncthreads();
+        for (int t = tid; t < B * n; t += nt) {
+            const int b = t / n, k = t % n;
+            double s = 0.0;
+            for (int j = 0; j < n; ++j) s += T1[b * n + j] * kinv[j * n + k];
+            A[t] = s;
+        }
+        // M = S - kvar (Ku + jitter)
+        for (int t = tid; t < n * n; t += nt) {
+            const int p = t / n, q = t % n;
+            M[t] = (double)qS[t] - kvar * (kern1(fabs((double)(p - q)) * step, isl) + (p == q ? a.jitter_ku : 0.0));
+        }
+        __syncthreads();
+        // f = A m ; T2 = A M
+        for (int b = tid; b < B; b += nt) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += A[b * n + k] * (double)qm[k];
+            if (o_fb) o_fb[(size_t)c * B + b] = s;
+            bm[b] += s;
+        }
+        for (int t = tid; t < B * n; t += nt) {
+            const int b = t / n, k = t % n;
+            double s = 0.0;
+            for (int j = 0; j < n; ++j) s += A[b * n + j] * M[j * n + k];
+            T2[t] = s;
+        }
+        // KL(N(m, S) || N(0, pv I)) through chol(S)
+        for (int t = tid; t < n * n; t += nt) Ls[t] = (double)qS[t];
+        __syncthreads();
+        chol_inplace(Ls, n);
+        double part = 0.0;
+        for (int t = tid; t < n * n; t += nt) {
+            const int p = t / n, q = t % n;
+            if (q <= p) part += Ls[t] * Ls[t] / a.prior_var;
+            if (q == p) part += -2.0 * log(Ls[t]) + (double)qm[p] * (double)qm[p] / a.prior_var;
+        }
+        const double tot = block_sum(part, red);
+        kl += 0.5 * (n * log(a.prior_var) + tot - n);
+    }
+    // beta_cov (+ jitter_b on the diagonal for the factorisation)
+    {
+        const double* A = W + w.A; const double* T2 = W + w.T2;
+        const double isl = 1.0 / sqrt(2.0) / ls;
+        const double s2 = std_ * std_;
+        for (long long t = tid; t < (long long)B * B; t += nt) {
+            const int i = (int)(t / B), j = (int)(t % B);
+            double v = (i == j) ? s2 * x[i] * x[i] : 0.0;
+            if (is_gp) {
+                double sg = kvar * kern1(x[j] - x[i], isl);
+                for (int k = 0; k < n; ++k) sg += T2[i * n + k] * A[j * n + k];
+                if (o_sg) o_sg[((size_t)c * B + i) * B + j] = sg;
+                v += sg;
+            }
+            if (o_bc) o_bc[((size_t)c * B + i) * B + j] = v;
+            Cm[t] = v + (i == j ? a.jitter_b : 0.0);
+        }
+        if (o_bm) for (int b = tid; b < B; b += nt) o_bm[(size_t)c * B + b] = bm[b];
+    }
+    __syncthreads();
+    chol_inplace(Cm, B);
+    if (in_lds) {
+        double* Lc = W + w.Lc;
+        for (long long t = tid; t < (long long)B * B; t += nt) Lc[t] = Cm[t];
+    }
+    // gain = beta_mean + L eps, then the HRF along the batch index
+    double* tv = W + w.v1;
+    for (int b = tid; b < B; b += nt) {
+        double s = bm[b];
+        for (int j = 0; j <= b; ++j) s += Cm[(long long)b * B + j] * e[j];
+        tv[b] = s;
+    }
+    __syncthreads();
+    for (int b = tid; b < B; b += nt) {
+        double s = tv[b];
+        if (is_hrf) {
+            s = 0.0;
+            for (int t = 0; t < a.taps && t <= b; ++t) s += a.hrf[t] * tv[b - t];
+        }
+        task_var[(size_t)c * B + b] = (float)s;
+    }
+    if (tid == 0) {
+        kl_part[c] = kl;
+        double* sc = W + w.sc;
+        sc[0] = sa; sc[1] = std_; sc[2] = kvar; sc[3] = ls; sc[4] = step;
+    }
+}
+
+__global__ void gain_kl_sum_k(const double* __restrict__ kl_part, int C, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int c = 0; c < C; ++c) s += kl_part[c];
+        out[0] = (float)s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// g_tv [C][B]: d loss / d gain (fp32),  g_kl [1]: d loss / d (sum of the KL terms).  Parameter gradients are added into G32
+// (the flat fp32 gradient buffer, same offsets as P).
+__global__ void __launch_bounds__(GP_T)
+gain_bwd_k(GainArgs a, const float* __restrict__ g_tv, const float* __restrict__ g_kl, float* __restrict__ G32) {
+    VG_DYN_SMEM(double, lds);
+    double* red = lds;
+    const int c = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int B = a.B, n = a.n;
+    const GpLayout w = gp_layout(B, n);
+    double* W = a.ws + (size_t)c * w.total;
+    const bool in_lds = B <= GP_LDS_MAXB;
+    double* Gm = in_lds ? lds + GP_T : W + w.G;                // d loss / d beta_cov, built in place
+    const long long* tb = a.tab + (size_t)c * TAB_W;
+    const bool is_gp = tb[0] != 0, is_hrf = tb[1] != 0;
+    const double* x = W + w.x; const double* e = W + w.e; const double* Lc = W + w.Lc;
+    const double* sc = W + w.sc;
+    const double sa = sc[0], std_ = sc[1], kvar = sc[2], ls = sc[3], step = sc[4];
+    const double gkl = (double)g_kl[0];
+    double* g = W + w.v1; double* u = W + w.v2; double* gin = W + w.v3;
+    // HRF transposed: g[i] = sum_t hk[t] gin[i + t]
+    for (int b = tid; b < B; b += nt) gin[b] = (double)g_tv[(size_t)c * B + b];
+    __syncthreads();
+    for (int b = tid; b < B; b += nt) {
+        double s = gin[b];
+        if (is_hrf) {
+            s = 0.0;
+            for (int t = 0; t < a.taps && b + t < B; ++t) s += a.hrf[t] * gin[b + t];
+        }
+        g[b] = s;
+    }
+    __syncthreads();
+    // u = L^T g ;  Phi = tril(u eps^T) with the diagonal halved  (L^T dL for dL = tril(g eps^T))
+    for (int i = tid; i < B; i += nt) {
+        double s = 0.0;
+        for (int k = i; k < B; ++k) s += Lc[(long long)k * B + i] * g[k];
+        u[i] = s;
+    }
+    __syncthreads();
+    for (long long t = tid; t < (long long)B * B; t += nt) {
+        const int i = (int)(t / B), j = (int)(t % B);
+        Gm[t] = (j < i) ? u[i] * e[j] : (j == i ? 0.5 * u[i] * e[i] : 0.0);
+    }
+    __syncthreads();
+    // S = L^-T Phi L^-1:  X = L^-T Phi;  S^T = L^-T X^T;  d beta_cov = (S + S^T) / 2
+    solve_LT_inplace(Lc, B, Gm, B, B);
+    for (long long t = tid; t < (long long)B * B; t += nt) {   // transpose in place (pairwise swap)
+        const int i = (int)(t / B), j = (int)(t % B);
+        if (j < i) { const double p = Gm[(long long)i * B + j]; Gm[(long long)i * B + j] = Gm[(long long)j * B + i]; Gm[(long long)j * B + i] = p; }
+    }
+    __syncthreads();
+    solve_LT_inplace(Lc, B, Gm, B, B);
+    for (long long t = tid; t < (long long)B * B; t += nt) {
+        const int i = (int)(t / B), j = (int)(t % B);
+        if (j < i) { const double s = 0.5 * (Gm[(long long)i * B + j] + Gm[(long long)j * B + i]); Gm[(long long)i * B + j] = s; Gm[(long long)j * B + i] = s; }
+    }
+    __syncthreads();
+    // linear gain: beta_mean = sa x, beta_cov diag = std^2 x^2, kl_lin(sa, std)
+    {
+        double p_sa = 0.0, p_sd = 0.0;
+        for (int b = tid; b < B; b += nt) { p_sa += g[b] * x[b]; p_sd += Gm[(long long)b * B + b] * x[b] * x[b]; }
+        const double s_sa = block_sum(p_sa, red), s_sd = block_sum(p_sd, red);
+        if (tid == 0) {
+            const double d_sa = s_sa + gkl * (sa - 1.0) / 0.25;
+            // d/dstd: 2 std * sum(..) + kl: 0.5 (2 std / 0.25 - 2 / std);  d std / d logstd = std
+            const double d_std = 2.0 * std_ * s_sd + gkl * 0.5 * (2.0 * std_ / 0.25 - 2.0 / std_);
+            G32[tb[3]] += (float)d_sa;
+            G32[tb[4]] += (float)(d_std * std_);
+        }
+    }
+    if (!is_gp) return;
+    const float* qm = a.P + tb[5];
+    const double* A = W + w.A; const double* kinv = W + w.kinv; const double* M = W + w.M; const double* Ls = W + w.Ls;
+    double* G2 = W + w.T1; double* gA = W + w.T2; double* gKnuT = W + w.T3; double* gM = W + w.N1; double* gKinv = W + w.N2;
+    const double isl = 1.0 / sqrt(2.0) / ls;
+    const float* xu = a.xu + (size_t)tb[2] * n;
+    const double xu0 = (double)xu[0];
+    // G2 = dSigma A  (dSigma symmetric)
+    for (int t = tid; t < B * n; t += nt) {
+        const int b = t / n, k = t % n;
+        double s = 0.0;
+        for (int j = 0; j < B; ++j) s += Gm[(long long)b * B + j] * A[j * n + k];
+        G2[t] = s;
+    }
+    __syncthreads();
+    // dM = A^T G2 ; dm = A^T g (+ KL) ; dA = g m^T + G2 (M + M^T)
+    for (int t = tid; t < n * n; t += nt) {
+        const int p = t / n, q = t % n;
+        double s = 0.0;
+        for (int b = 0; b < B; ++b) s += A[b * n + p] * G2[b * n + q];
+        gM[t] = s;
+    }
+    for (int k = tid; k < n; k += nt) {
+        double s = 0.0;
+        for (int b = 0; b < B; ++b) s += A[b * n + k] * g[b];
+        G32[tb[5] + k] += (float)(s + gkl * (double)qm[k] / a.prior_var);
+    }
+    for (int t = tid; t < B * n; t += nt) {
+        const int b = t / n, k = t % n;
+        double s = g[b] * (double)qm[k];
+        for (int j = 0; j < n; ++j) s += G2[b * n + j] * (M[j * n + k] + M[k * n + j]);
+        gA[t] = s;
+    }
+    __syncthreads();
+    // dS = dM + gkl * 0.5 (I / pv - S^-1),  S^-1 from chol(S)
+    double* tmp = W + w.N3; double* Sinv = W + w.N4;
+    spd_inverse_from_chol(Ls, n, tmp, Sinv);
+    for (int t = tid; t < n * n; t += nt) {
+        const int p = t / n, q = t % n;
+        G32[tb[6] + t] += (float)(gM[t] + gkl * 0.5 * ((p == q ? 1.0 / a.prior_var : 0.0) - Sinv[t]));
+    }
+    // d kvar = sum dSigma . Knn1  -  sum dM . (Ku1 + jitter)
+    double p_kv = 0.0, p_ls = 0.0;
+    for (long long t = tid; t < (long long)B * B; t += nt) {
+        const int i = (int)(t / B), j = (int)(t % B);
+        const double d = x[j] - x[i], kv = kern1(d, isl), gs = Gm[t];
+        p_kv += gs * kv;
+        p_ls += kvar * gs * kv * d * d;                        // d Knn / d ls = Knn d^2 / ls^3  (the 1/ls^3 is applied at the end)
+    }
+    for (int t = tid; t < n * n; t += nt) {
+        const int p = t / n, q = t % n;
+        const double d = fabs((double)(p - q)) * step;
+        p_kv -= gM[t] * (kern1(d, isl) + (p == q ? a.jitter_ku : 0.0));
+    }
+    // A = Knu^T Kinv:  dKnu^T = dA Kinv^T ;  dKinv = Knu dA ;  dKu = -Kinv^T dKinv Kinv^T - kvar dM
+    for (int t = tid; t < B * n; t += nt) {
+        const int b = t / n, k = t % n;
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) s += gA[b * n + j] * kinv[k * n + j];
+        gKnuT[t] = s;
+    }
+    for (int t = tid; t < n * n; t += nt) {
+        const int p = t / n, q = t % n;
+        double s = 0.0;
+        for (int b = 0; b < B; ++b) {
+            s += kern1(knu_dist(xu0, x[b], p, step, a.jitter_ku == 0.0), isl) * gA[b * n + q];
+        }
+        gKinv[t] = s;
+    }
+    __syncthreads();
+    for (int t = tid; t < B * n; t += nt) {
+        const int b = t / n, k = t % n;
+        const double d = knu_dist(xu0, x[b], k, step, a.jitter_ku == 0.0);
+        p_ls += gKnuT[t] * kern1(d, isl) * d * d;
+    }
+    for (int t = tid; t < n * n; t += nt) {                    // tmp = Kinv^T dKinv
+        const int p = t / n, q = t % n;
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) s += kinv[j * n + p] * gKinv[j * n + q];
+        tmp[t] = s;
+    }
+    __syncthreads();
+    for (int t = tid; t < n * n; t += nt) {
+        const int p = t / n, q = t % n;
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) s += tmp[p * n + j] * kinv[q * n + j];
+        const double gku = -s - kvar * gM[t];
+        const double d = fabs((double)(p - q)) * step;
+        p_ls += gku * kern1(d, isl) * d * d;
+    }
+    const double s_kv = block_sum(p_kv, red), s_ls = block_sum(p_ls, red);
+    if (tid == 0) {
+        const double lk = (double)a.P[tb[7]], ll = (double)a.P[tb[8]];
+        G32[tb[7]] += (float)(s_kv * exp(lk));                                  // kvar = exp(logkvar) + 0.1
+        const double sg = ls / 3.0;                                             // ls = 3 sigmoid(exp(log_ls) + 0.5)
+        G32[tb[8]] += (float)(s_ls / (ls * ls * ls) * 3.0 * sg * (1.0 - sg) * exp(ll));
+    }
+}
+
+GainArgs mk_args(const vg_gain_desc* d, const int64_t* table, const float* params, const float* xu, const float* cov, int64_t ldc,
+                 const float* eps, const double* hrf, double* ws) {
+    GainArgs a;
+    a.C = d->C; a.B = d->B; a.n = d->n; a.taps = d->hrf_taps;
+    a.jitter_b = d->jitter_b; a.jitter_ku = d->jitter_ku; a.prior_var = d->prior_var;
+    a.tab = (const long long*)table; a.P = params; a.xu = xu; a.cov = cov; a.ldc = ldc; a.eps = eps; a.hrf = hrf; a.ws = ws;
+    return a;
+}
+
+size_t lds_bytes(int B) { return (size_t)(GP_T + (B <= GP_LDS_MAXB ? (size_t)B * B : 0)) * sizeof(double); }
+
+int check(const vg_gain_desc* d, const char* who) {
+    if (!d || d->C <= 0 || d->B <= 0 || d->n < 2 || d->n > 128 || d->B > 4096 || d->hrf_taps < 0 || !(d->prior_var > 0)) {
+        vg_set_error("%s: bad descriptor", who); return VG_ERR_ARG;
+    }
+    return VG_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t vg_gp_gain_ws_bytes(int32_t C, int32_t B, int32_t n) {
+    if (C <= 0 || B <= 0 || n < 2) return -1;
+    GpLayout w = gp_layout(B, n);
+    return (int64_t)(w.total * C + C + 8) * (int64_t)sizeof(double);       // C slabs + the per-covariate KL terms
+}
+
+extern "C" int vg_gp_gain_fwd(const vg_gain_desc* d, const int64_t* table, const float* params, const float* xu,
+                              const float* covariates, int64_t ld_cov, const float* eps_beta, const double* hrf_taps, void* ws,
+                              float* task_var, float* gp_kl, double* beta_mean, double* beta_cov, double* f_bar, double* Sigma,
+                              void* stream) {
+    int rc = check(d, "vg_gp_gain_fwd");
+    if (rc) return rc;
+    if (!table || !params || !covariates || !eps_beta || !ws || !task_var || !gp_kl || (d->hrf_taps > 0 && !hrf_taps)) {
+        vg_set_error("vg_gp_gain_fwd: null argument"); return VG_ERR_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    GpLayout w = gp_layout(d->B, d->n);
+    double* wsd = (double*)ws;
+    double* kl_part = wsd + (size_t)w.total * d->C;
+    GainArgs a = mk_args(d, table, params, xu, covariates, ld_cov, eps_beta, hrf_taps, wsd);
+    vg_launch(gain_fwd_k, dim3(d->C), dim3(GP_T), lds_bytes(d->B), s, a, task_var, kl_part, beta_mean, beta_cov, f_bar, Sigma);
+    rc = vg_check_launch("gp_gain_fwd");
+    if (rc) return rc;
+    vg_launch(gain_kl_sum_k, dim3(1), dim3(64), 0, s, (const double*)kl_part, (int)d->C, gp_kl);
+    return vg_check_launch("gp_gain_kl_sum");
+}
+
+extern "C" int vg_gp_gain_bwd(const vg_gain_desc* d, const int64_t* table, const float* params, const float* xu,
+                              const float* covariates, int64_t ld_cov, const float* eps_beta, const double* hrf_taps, void* ws,
+                              const float* g_task_var, const float* g_gp_kl, float* flat_grads, void* stream) {
+    int rc = check(d, "vg_gp_gain_bwd");
+    if (rc) return rc;
+    if (!table || !params || !covariates || !eps_beta || !ws || !g_task_var || !g_gp_kl || !flat_grads) {
+        vg_set_error("vg_gp_gain_bwd: null argument"); return VG_ERR_ARG;
+    }
+    GainArgs a = mk_args(d, table, params, xu, covariates, ld_cov, eps_beta, hrf_taps, (double*)ws);
+    vg_launch(gain_bwd_k, dim3(d->C), dim3(GP_T), lds_bytes(d->B), (hipStream_t)stream, a, g_task_var, g_gp_kl, flat_grads);
+    return vg_check_launch("gp_gain_bwd");
+}

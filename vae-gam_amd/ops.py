@@ -770,6 +770,70 @@ def cholesky(a):
     return torch.linalg.cholesky_ex(a, check_errors=False).L
 
 
+class GainConsts:
+    """Device-side constants of the gain block of one model: the parameter-offset table, the inducing grids, the HRF taps."""
+
+    def __init__(self, table, xu, hrf, n, jitter_ku=0.0, jitter_b=1e-5, prior_var=10.0):
+        self.table, self.xu, self.hrf = table, xu, hrf            # int64 [C][10], fp32 [K][n] (or None), float64 [taps]
+        self.C, self.n = int(table.shape[0]), int(n)
+        self.jitter_ku, self.jitter_b, self.prior_var = float(jitter_ku), float(jitter_b), float(prior_var)
+
+    def desc(self, B):
+        return _lib.GainDesc(self.C, int(B), self.n, int(self.hrf.numel()), self.jitter_b, self.jitter_ku, self.prior_var)
+
+
+class GpGain(torch.autograd.Function):
+    """(covariates (B, >=C) fp32, eps_beta (C, B) fp32) -> gains task_var (C, B) fp32, gp_kl (1,) fp32 and float64 copies of
+    beta_mean (C,B), beta_cov (C,B,B), f_bar (C,B), Sigma (C,B,B), kl terms (C,) for exports / tests: vg_gp_gain_fwd, one
+    workgroup per covariate (vae_reg_GP.py:345-378, gp.py:41-110).  The backward launch adds the gain-parameter gradients
+    straight into the flat fp32 gradient buffer; `params` are listed only so that autograd calls it.
+    `join_stream`: the stream that must wait for the backward launch (the model runs this block on a second stream)."""
+
+    @staticmethod
+    def forward(ctx, covariates, eps_beta, consts, flat_p, flat_g, join_stream, *params):
+        lib = _lib.get_lib()
+        B = covariates.shape[0]
+        C = consts.C
+        assert covariates.dtype == torch.float32 and covariates.dim() == 2 and covariates.shape[1] >= C and covariates.stride(1) == 1
+        eps_beta = _chk(eps_beta.contiguous())
+        assert eps_beta.shape == (C, B)
+        dev = covariates.device
+        d = consts.desc(B)
+        ws = torch.empty(lib.size('vg_gp_gain_ws_bytes', C, B, consts.n) // 8, dtype=torch.float64, device=dev)
+        tv = torch.empty((C, B), dtype=torch.float32, device=dev)
+        kl = torch.empty(1, dtype=torch.float32, device=dev)
+        bm = torch.empty((C, B), dtype=torch.float64, device=dev)
+        bc = torch.empty((C, B, B), dtype=torch.float64, device=dev)
+        fb = torch.zeros((C, B), dtype=torch.float64, device=dev)
+        sg = torch.zeros((C, B, B), dtype=torch.float64, device=dev)
+        _call(covariates, 'vg_gp_gain_fwd', ctypes.byref(d), _p(consts.table), _p(flat_p), _p(consts.xu), _p(covariates),
+              int(covariates.stride(0)), _p(eps_beta), _p(consts.hrf), _p(ws), _p(tv), _p(kl), _p(bm), _p(bc), _p(fb), _p(sg))
+        kl_terms = ws[-(C + 8):-8]                                # per-covariate kl_lin (+ kl_gp), float64
+        ctx.save_for_backward(covariates, eps_beta, ws)
+        ctx.consts, ctx.flat_p, ctx.flat_g, ctx.join_stream = consts, flat_p, flat_g, join_stream
+        ctx.mark_non_differentiable(bm, bc, fb, sg, kl_terms)
+        return tv, kl, bm, bc, fb, sg, kl_terms
+
+    @staticmethod
+    def backward(ctx, g_tv, g_kl, *_):
+        covariates, eps_beta, ws = ctx.saved_tensors
+        consts = ctx.consts
+        B = covariates.shape[0]
+        d = consts.desc(B)
+        if g_tv is None:
+            g_tv = torch.zeros((consts.C, B), dtype=torch.float32, device=covariates.device)
+        if g_kl is None:
+            g_kl = torch.zeros(1, dtype=torch.float32, device=covariates.device)
+        g_tv = _chk(g_tv.contiguous()); g_kl = _chk(g_kl.contiguous())
+        _call(covariates, 'vg_gp_gain_bwd', ctypes.byref(d), _p(consts.table), _p(ctx.flat_p), _p(consts.xu), _p(covariates),
+              int(covariates.stride(0)), _p(eps_beta), _p(consts.hrf), _p(ws), _p(g_tv), _p(g_kl), _p(ctx.flat_g))
+        if ctx.join_stream is not None and covariates.is_cuda:
+            cur = torch.cuda.current_stream(covariates.device)
+            if cur != ctx.join_stream:
+                ctx.join_stream.wait_stream(cur)               # the gradients are written outside autograd's own stream bookkeeping
+        return (None,) * len(ctx.needs_input_grad)
+
+
 def adam_advance_(state, lr, b1, b2):
     """state = double[3] {lr/(1-b1^t), sqrt(1-b2^t), t} on the device: t += 1, scalars refreshed (one thread)."""
     _call(state, 'vg_adam_advance', _p(_chk(state, torch.float64)), float(lr), float(b1), float(b2))

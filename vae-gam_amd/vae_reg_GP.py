@@ -87,16 +87,20 @@ class VAE(nn.Module):
     def __init__(self, nf=8, save_dir='', lr=1e-3, num_covariates=8, num_latents=32, device_name="auto",
                  num_inducing_pts=6, gp_kl_scale=10.0, glm_maps='', glm_reg_scale=1.0, csv_files='',
                  neural_covariates=True, *, img_shape=IMG_SHAPE, xu_ranges=None, tensorboard=False,
-                 data_parallel=None):
+                 data_parallel=None, gp_jitter=0.0):
         """Arguments up to `neural_covariates` are the reference's (vae_reg_GP.py:36-37).
         Keyword-only extensions: `img_shape` (41x49x35 or 82x98x70), `xu_ranges` (inducing-point
         ranges given directly instead of read from `csv_files`), `tensorboard` (off by default),
-        `data_parallel` (a dp.DataParallelContext).  `glm_maps` may be a CSV path (reference) or an
-        array of shape (V, C+1) whose column 0 is the CSV index column."""
+        `data_parallel` (a dp.DataParallelContext), `gp_jitter` (0 = the reference's plain inverse of the
+        inducing-point kernel matrix Ku, gp.py:104-107; > 0: Ku + gp_jitter*I on the unit-variance scale, i.e. the
+        inducing prior k_var*(Ku + jitter I), factorised by Cholesky -- needed where the inducing grid is dense against the
+        length scale and Ku is singular in any precision, e.g. 64 points).  `glm_maps` may be a CSV path
+        (reference) or an array of shape (V, C+1) whose column 0 is the CSV index column."""
         super(VAE, self).__init__()
         self.nf, self.save_dir, self.lr = nf, save_dir, lr
         self.num_covariates, self.num_latents = num_covariates, num_latents
         self.neural_covariates = neural_covariates
+        self.gp_jitter = float(gp_jitter)
         self.z_dim = self.num_latents + self.num_covariates + 1
         self.img_shape = tuple(int(v) for v in img_shape)
         self.img_dim = int(np.prod(self.img_shape))
@@ -356,52 +360,20 @@ class VAE(nn.Module):
                 'eps_d': torch.randn(B, self.num_latents, device=device, generator=gen),
                 'eps_beta': torch.randn(self.num_covariates, B, device=device, generator=gen)}
 
-    def _gains(self, covariates, eps_beta):
-        """All C gains of a minibatch at once (vae_reg_GP.py:345-378).
-        covariates (B, C) -> task_var (C, B), gp_kl_loss (1,), and the per-covariate beta mean/cov."""
-        B, C = covariates.shape[0], self.num_covariates
-        dev = covariates.device
-        names = [c.name for c in self.schema]
-        # This block is a few KB of dense algebra per step but numerically the most fragile part of the
-        # model: the BxB gain covariance is close to singular (1e-5 jitter, vae_reg_GP.py:368) and in fp32
-        # the reference's own gradients through its Cholesky are rounding noise at batch 32 (SURVEY H2,
-        # tests/test_model_gpu.py).  It is evaluated in float64 here -- free on MI355X at this size --
-        # and handed to the fp32 kernels as fp32; parameters and their gradients stay fp32.
-        f64 = torch.float64
-        xq = covariates.t().contiguous().to(f64)                                            # (C, B)
-        sa = torch.cat([self.gp_params[n]['sa'][0] for n in names]).to(f64)                 # (C,)
-        std = torch.cat([self.gp_params[n]['logstd'][0] for n in names]).to(f64).exp()
-        gp_kl_loss = self.calc_linW_KL(sa, std).sum().reshape(1)                            # :346-348
-        beta_mean = sa.unsqueeze(1) * xq                                                    # :349
-        eye = torch.eye(B, device=dev, dtype=f64)
-        beta_cov = (std.pow(2).unsqueeze(1) * xq.pow(2)).unsqueeze(-1) * eye                # :350-351 (diagonal)
-        gidx = [i for i, c in enumerate(self.schema) if c.gp]
-        K = self._gain_consts(dev)               # selector tensors built once (host lists would force H2D copies, which a hipGraph capture refuses)
+    def _gains(self, covariates, eps_beta, join_stream=None):
+        """All C gains of a minibatch at once (vae_reg_GP.py:345-378): ONE launch, one workgroup per covariate
+        (ops.GpGain -> vg_gp_gain_fwd / _bwd; float64 arithmetic).
+        covariates (B, >=C) fp32 -> task_var (C, B) fp32, gp_kl_loss (1,) fp32, beta mean / covariance (float64) and the
+        GP posteriors of the continuous covariates ((names, f_bar (K,B), Sigma (K,B,B)) or None)."""
+        K = self._gain_consts(covariates.device)
+        g32 = self.optimizer.groups[torch.float32]
+        params = [p for n in K['names'] for p in self.gp_params[n].values() if isinstance(p, torch.nn.Parameter)]
+        tv, kl, bm, bc, fb, sg, kl_terms = ops.GpGain.apply(covariates, eps_beta, K['consts'], g32['p'], g32['g'], join_stream, *params)
+        self.last_gp_kl = kl_terms                      # per covariate: kl_lin (+ kl_gp), float64 (parity tests, logging)
         post = None
-        if gidx:
-            gn = [names[i] for i in gidx]
-            xu = torch.stack([self.gp_params[n]['xu'] for n in gn])
-            kvar = torch.stack([self.gp_params[n]['logkvar'] for n in gn]).to(f64).exp() + 0.1     # :355
-            ls = 3.0 * torch.sigmoid(torch.stack([self.gp_params[n]['log_ls'] for n in gn]).to(f64).exp() + 0.5)  # :357
-            qu_m = torch.cat([self.gp_params[n]['qu_m'] for n in gn]).to(f64)
-            qu_S = torch.stack([self.gp_params[n]['qu_S'] for n in gn]).to(f64)
-            f_bar, Sigma = gp.posterior_batched(xu, kvar, ls, qu_m, qu_S, xq.index_select(0, K['gidx']))
-            sel = K['sel']
-            beta_mean = beta_mean + sel @ f_bar                                             # :363
-            beta_cov = beta_cov + (sel @ Sigma.reshape(len(gidx), -1)).reshape(C, B, B)     # :364
-            kls = gp.kl_batched(qu_m, qu_S)
-            self.last_gp_kl = kls.detach()                                                  # per-covariate KL terms (parity tests, logging)
-            gp_kl_loss = gp_kl_loss + kls.sum()                                             # :366-367
-            post = (gn, f_bar, Sigma)
-        L = ops.cholesky(beta_cov + 1e-5 * eye)                                             # :368
-        task_var = beta_mean + (L @ eps_beta.to(f64).unsqueeze(-1)).squeeze(-1)             # :369
-        hidx = [i for i, c in enumerate(self.schema) if c.hrf]
-        if hidx:                                                                            # :377-378
-            T = self._hrf_matrix(B, dev).to(f64)
-            conv = task_var @ T
-            m = K['hrf_mask']
-            task_var = m * conv + (1 - m) * task_var
-        return task_var.float(), gp_kl_loss.float(), beta_mean, beta_cov, post
+        if K['gidx_list']:
+            post = ([K['names'][i] for i in K['gidx_list']], fb.index_select(0, K['gidx']), sg.index_select(0, K['gidx']))
+        return tv, kl, bm, bc, post
 
     def _gains_stream(self, dev):
         if dev.type != 'cuda' or not self.overlap_gains:
@@ -412,19 +384,28 @@ class VAE(nn.Module):
         return self._gain_streams[key]
 
     def _gain_consts(self, dev):
+        """Per device, built once: the table of gain-parameter offsets inside the flat fp32 parameter buffer, the stacked
+        inducing grids and the HRF taps (fp32-rounded as the reference's Toeplitz matrix, vae_reg_GP.py:297-299)."""
         key = str(dev)
         if key not in self._gain_const_cache:
-            C = self.num_covariates
+            names = [c.name for c in self.schema]
+            g32 = self.optimizer.groups[torch.float32]
+            off = {self.optimizer.names[i]: g32['offs'][k] for k, i in enumerate(g32['idx'])}
             gidx = [i for i, c in enumerate(self.schema) if c.gp]
-            hidx = [i for i, c in enumerate(self.schema) if c.hrf]
-            sel = torch.zeros(C, max(len(gidx), 1), dtype=torch.float64)
-            for j, i in enumerate(gidx):
-                sel[i, j] = 1.0
-            m = torch.zeros(C, 1, dtype=torch.float64)
-            for i in hidx:
-                m[i] = 1.0
-            self._gain_const_cache[key] = {'gidx': torch.tensor(gidx, dtype=torch.int64).to(dev), 'sel': sel.to(dev),
-                                           'hrf_mask': m.to(dev)}
+            rows = []
+            for i, c in enumerate(self.schema):
+                if c.gp:
+                    rows.append([1, int(c.hrf), gidx.index(i), off['sa_' + c.name], off['logstd_' + c.name], off['qu_m_' + c.name],
+                                 off['qu_S_' + c.name], off['logkvar_' + c.name], off['logls_' + c.name], 0])
+                else:
+                    rows.append([0, int(c.hrf), 0, off['sa_' + c.name], off['logstd_' + c.name], 0, 0, 0, 0, 0])
+            table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            xu = torch.stack([self.gp_params[names[i]]['xu'].float() for i in gidx]).contiguous().to(dev) if gidx else None
+            hrf = torch.tensor(utils.hrf(np.arange(0, 20, 1.4))).float().double().to(dev) if any(c.hrf for c in self.schema) \
+                else torch.zeros(0, dtype=torch.float64, device=dev)
+            consts = ops.GainConsts(table, xu, hrf, self.inducing_pts, jitter_ku=self.gp_jitter)
+            self._gain_const_cache[key] = {'consts': consts, 'names': names, 'gidx_list': gidx,
+                                           'gidx': torch.tensor(gidx, dtype=torch.int64).to(dev)}
         return self._gain_const_cache[key]
 
     def _glm(self):
@@ -452,14 +433,16 @@ class VAE(nn.Module):
         if noise is None:
             noise = self.draw_noise(Bg, dev)
         eps_w, eps_d = noise['eps_w'][lo:lo + B], noise['eps_d'][lo:lo + B]
-        # The gain algebra is a few hundred tiny fp64 launches that depend only on the covariates and the gain
-        # parameters: it is queued on a second HIP stream beside the encoder/decoder (autograd replays its backward on
-        # that stream too, beside the decoder's backward), and joined where the fused GAM/ELBO kernel needs the gains.
+        # The gain block (one launch forward, one backward; a single workgroup per covariate walking B serial Cholesky /
+        # substitution steps) depends only on the covariates and the gain parameters: it is queued on a second HIP stream
+        # beside the encoder/decoder (autograd replays its backward on that stream too, beside the decoder's backward), and
+        # joined where the fused GAM/ELBO kernel needs the gains.
         gains_stream = self._gains_stream(dev)
         if gains_stream is not None:
-            gains_stream.wait_stream(torch.cuda.current_stream(dev))
+            main = torch.cuda.current_stream(dev)
+            gains_stream.wait_stream(main)
             with torch.cuda.stream(gains_stream):
-                gains = self._gains(covariates, noise['eps_beta'])
+                gains = self._gains(covariates, noise['eps_beta'], join_stream=main)
         else:
             gains = self._gains(covariates, noise['eps_beta'])
         heads = self._encode_heads(x, stacked=True)
