@@ -116,6 +116,22 @@ int vg_bn_bwd_apply(float* dxe_inout, const float* p, int32_t N, int32_t C, int6
                     const double* sums, double count, float* dgamma_part, float* dbeta_part,
                     void* ws, float* chsum, int32_t chsum_accumulate, void* stream);
 
+/* Batch-norm backward FUSED with the data gradient of a one-output-channel 3x3x3 stride-1 ConvTranspose3d behind it -- the
+ * decoder's last stage, bnt5 -> convt5 (vae_reg_GP.py:218,264), on the largest activation of the network.  The gradient that
+ * reaches the batch norm, dxe[n][c][q] = sum_k dy[n][0][q + k] * w[c][0][k] (what autograd's conv_transpose3d backward / vg_corr3d
+ * would write as a C-channel tensor), is recomputed from a dy tile in LDS inside both passes instead of being stored and re-read:
+ *   p   [N][C][ID][IH][IW] the stored pre-activation;  dy [N][1][ID+2][IH+2][IW+2];  w [C][27] (the layer's own weight layout);
+ *   reduce: sums[g][c] = {sum dxe, sum dxe*hhat}  (double[G][C][2], as vg_bn_bwd_reduce);
+ *   apply : dp[N][C][...] = relu'(p) * gamma*rstd * (dxe - mean(dxe) - hhat*mean(dxe*hhat))  (as vg_bn_bwd_apply, out of place),
+ *           chsum[c] (+)= per-channel sum of dp (bias gradient of the layer that produced p; NULL = not wanted).
+ * ws: vg_bn_tconv1_ws_bytes(N, C, ID, per_group) bytes.  Data-parallel callers all-reduce `sums` between the two calls. */
+int64_t vg_bn_tconv1_ws_bytes(int32_t N, int32_t C, int32_t ID, int32_t per_group);
+int vg_bn_bwd_reduce_tconv1(const float* dy, const float* w, const float* p, int32_t N, int32_t C, int32_t ID, int32_t IH, int32_t IW,
+                            int32_t per_group, int32_t relu, const float* mean, const float* rstd, void* ws, double* sums, void* stream);
+int vg_bn_bwd_apply_tconv1(const float* dy, const float* w, const float* p, float* dp, int32_t N, int32_t C, int32_t ID, int32_t IH,
+                           int32_t IW, int32_t per_group, int32_t relu, const float* gamma, const float* mean, const float* rstd,
+                           const double* sums, double count, void* ws, float* chsum, int32_t chsum_accumulate, void* stream);
+
 /* per-channel sum of a [N][C][P] tensor (bias gradients): out[c] = sum_{n,p} x[n][c][p] */
 int vg_channel_sum(const float* x, int32_t N, int32_t C, int64_t P, void* ws, float* out, int32_t accumulate, void* stream);
 

@@ -47,6 +47,9 @@ _PROTOS = {
     'vg_bn_finalize': (ctypes.c_int, [vp, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp]),
     'vg_bn_bwd_reduce': (ctypes.c_int, [vp, vp, i32, i32, i64, i32, i32, vp, vp, vp, vp, vp]),
     'vg_bn_bwd_apply': (ctypes.c_int, [vp, vp, i32, i32, i64, i32, i32, vp, vp, vp, vp, f64, vp, vp, vp, vp, i32, vp]),
+    'vg_bn_tconv1_ws_bytes': (i64, [i32, i32, i32, i32]),
+    'vg_bn_bwd_reduce_tconv1': (ctypes.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    'vg_bn_bwd_apply_tconv1': (ctypes.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, f64, vp, vp, i32, vp]),
     'vg_bn_param_grad': (ctypes.c_int, [vp, i32, i32, vp, vp, i32, vp]),
     'vg_latent_fwd': (ctypes.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     'vg_latent_bwd': (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),

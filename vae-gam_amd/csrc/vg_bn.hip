@@ -279,6 +279,258 @@ extern "C" int vg_bn_bwd_apply(float* dxe, const float* p, int32_t N, int32_t C,
 }
 
 namespace {
+// ------------------------------------------------------------------------------------------------------------------
+// Batch-norm backward FUSED with the data gradient of the layer behind it, for the decoder's last stage
+// (bnt5 -> convt5, vae_reg_GP.py:218,264: ConvTranspose3d(C, 1, 3, stride 1) on the largest activation of the network).
+// The gradient reaching the batch norm,  dxe[n][c][q] = sum_k dy[n][q + k] * w[c][k]  (27 taps of a ONE-channel tensor),
+// is cheaper to recompute from dy than to store and re-read: both passes below form it on the fly from a dy tile staged in
+// LDS, so the C-channel gradient tensor is never written (one full-size write and two full-size reads less per step),
+// and the separate data-gradient launch disappears.
+//   pass 1 (reduce): reads dy + p           -> per (group, channel) [sum dxe, sum dxe*hhat]
+//   pass 2 (apply) : reads dy + p, writes dp = relu'(p) * gamma*rstd * (dxe - m1 - hhat*m2)   (+ per-channel sum of dp)
+// grid (d-tiles, N): a block owns TD planes of one sample's p (all rows / columns); it stages the TD+2 dy planes they touch --
+// ONE contiguous span -- by flat LDS-DMA; a thread walks flattened positions (coalesced loads of p, stores of dp).
+constexpr int FT_TD = 3;                         // planes of p per block (39 = 13 x 3; 80 = 26 x 3 + 2)
+constexpr int FT_MAXC = 16;
+
+struct FtParams {
+    int N, C, ID, IH, IW;                        // p: [N][C][ID][IH][IW];  dy: [N][1][ID+2][IH+2][IW+2]
+    int per_group, relu, tilesD;
+    float inv_iw, inv_plane;                     // 1/IW, 1/(IH*IW) for the position decode
+};
+
+// a wave-uniform value pinned to a VECTOR register: the per-channel constants below are uniform, the compiler would keep all of them in
+// scalar registers next to the 27 weights of the running channel, run out of SGPRs and spill them into VGPR lanes (v_readlane per use)
+#ifdef VG_EMU
+static inline float to_vgpr(float v) { return v; }
+#else
+__device__ __forceinline__ float to_vgpr(float v) { float r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v)); return r; }
+#endif
+
+// MODE 0: reduce, MODE 1: apply
+template <int MODE, int CT>
+__global__ void __launch_bounds__(BN_THREADS)
+bn_tconv1_k(const float* __restrict__ dy, const float* __restrict__ w, const float* __restrict__ p, float* __restrict__ dp,
+            const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+            const double* __restrict__ sums, double count, FtParams a, double* __restrict__ part, double* __restrict__ csum_part) {
+    VG_DYN_SMEM(float, tile);
+    const int tid = threadIdx.x, lane = tid % VG_WAVE, wave = vg_wave_id();
+    const int n = blockIdx.y, td = blockIdx.x;
+    const int C = CT ? CT : a.C;
+    const int g = n / a.per_group;
+    const int OH = a.IH + 2, OW = a.IW + 2, oplane = OH * OW, iplane = a.IH * a.IW;
+    const int d0 = td * FT_TD, nd = min(FT_TD, a.ID - d0);
+    // ---- stage dy planes [d0, d0 + nd + 2): contiguous
+    {
+        const float* src = dy + ((size_t)n * (a.ID + 2) + d0) * oplane;
+        const int nfl = (nd + 2) * oplane;
+        for (int o = wave * VG_WAVE; o < nfl; o += BN_THREADS)
+            if (o + lane < nfl) vg_dma4(src + o + lane, tile + o);
+        vg_dma_wait();
+    }
+    __syncthreads();
+    float mu[CT ? CT : FT_MAXC], rs[CT ? CT : FT_MAXC], k1[CT ? CT : FT_MAXC], m1[CT ? CT : FT_MAXC], m2[CT ? CT : FT_MAXC];
+    float acc0[CT ? CT : FT_MAXC], acc1[CT ? CT : FT_MAXC];
+#pragma unroll
+    for (int c = 0; c < (CT ? CT : FT_MAXC); ++c) {
+        if (c < C) {
+            const int gc = g * C + c;
+            mu[c] = to_vgpr(mean[gc]); rs[c] = to_vgpr(rstd[gc]);
+            if (MODE == 1) {
+                m1[c] = to_vgpr((float)(sums[(size_t)gc * 2] / count)); m2[c] = to_vgpr((float)(sums[(size_t)gc * 2 + 1] / count));
+                k1[c] = to_vgpr((gamma ? gamma[c] : 1.f) * rstd[gc]);
+            }
+        }
+        acc0[c] = 0.f; acc1[c] = 0.f;
+    }
+    const int npos = nd * iplane;
+    const float lo = a.relu ? 0.f : -__builtin_inff();
+    const size_t vol = (size_t)a.ID * iplane;
+    const float* pb = p + (size_t)n * C * vol + (size_t)d0 * iplane;
+    float* dpb = MODE == 1 ? dp + (size_t)n * C * vol + (size_t)d0 * iplane : nullptr;
+    // PP positions per thread and iteration (strided by the block: every load / store stays coalesced): the 27 weights of a channel
+    // are fetched through the scalar path once per iteration and used for PP positions.  All C*27 weights do not fit the scalar
+    // registers; left to itself the compiler hoists them out of the loop anyway and spills them into VGPR lanes (210 v_readlane
+    // per position in the first version of this kernel) -- the pointer is laundered per channel so that they are re-loaded.
+    constexpr int PP = 2;
+    for (int e0 = tid; e0 < npos; e0 += PP * BN_THREADS) {
+        int ee[PP]; bool ok[PP]; int toff[PP];
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            const int e = e0 + u * BN_THREADS;
+            ok[u] = e < npos;
+            ee[u] = ok[u] ? e : e0;
+            // e -> (dl, h, x): float reciprocal estimate + one correction step (exact for these sizes)
+            int dl = (int)((float)ee[u] * a.inv_plane);
+            int r = ee[u] - dl * iplane;
+            dl += (r >= iplane ? 1 : 0) - (r < 0 ? 1 : 0);                  // branch-free correction of the estimate
+            r = ee[u] - dl * iplane;
+            int h = (int)((float)r * a.inv_iw);
+            int x = r - h * a.IW;
+            h += (x >= a.IW ? 1 : 0) - (x < 0 ? 1 : 0);
+            x = r - h * a.IW;
+            toff[u] = dl * oplane + h * OW + x;
+        }
+        float pv[PP][CT ? CT : FT_MAXC];
+#pragma unroll
+        for (int u = 0; u < PP; ++u)
+#pragma unroll
+            for (int c = 0; c < (CT ? CT : FT_MAXC); ++c) if (c < C) pv[u][c] = pb[(size_t)c * vol + ee[u]];
+        // the 27 dy values each position's gradient is made of (shared by all channels)
+        float win[PP][27];
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            const float* t0 = tile + toff[u];
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const float* row = t0 + kd * oplane + kh * OW;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) win[u][(kd * 3 + kh) * 3 + kw] = row[kw];
+                }
+        }
+        // channel loop, software-pipelined by hand: the 27 weights of channel c+1 are requested (scalar loads) before the FMAs of
+        // channel c; sched_barrier keeps the compiler from pulling ALL channels' loads to the top of the iteration (216 scalar
+        // registers do not exist: it then spills them through VGPR lanes)
+        float wcur[27], wnxt[27];
+        {
+            vg_cptr w0 = VG_CPTR(w);
+#pragma unroll
+            for (int k = 0; k < 27; ++k) wcur[k] = w0[k];
+        }
+#pragma unroll
+        for (int c = 0; c < (CT ? CT : FT_MAXC); ++c) {
+            if (c >= C) continue;
+#ifndef VG_EMU
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (c + 1 < C) {
+                int coff = (c + 1) * 27;
+#ifndef VG_EMU
+                asm volatile("" : "+s"(coff));
+#endif
+                vg_cptr wn = VG_CPTR(w) + coff;
+#pragma unroll
+                for (int k = 0; k < 27; ++k) wnxt[k] = wn[k];
+            }
+            float dxe[PP];
+#pragma unroll
+            for (int u = 0; u < PP; ++u) dxe[u] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 27; ++k) {
+#pragma unroll
+                for (int u = 0; u < PP; ++u) dxe[u] = fmaf(win[u][k], wcur[k], dxe[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < PP; ++u) {
+                const float hv = vg_max(pv[u][c], lo);
+                const float hh = (hv - mu[c]) * rs[c];
+                if (MODE == 0) {
+                    const float dm = ok[u] ? dxe[u] : 0.f;
+                    acc0[c] += dm; acc1[c] = fmaf(dm, hh, acc1[c]);
+                } else {
+                    float v = k1[c] * (dxe[u] - m1[c] - hh * m2[c]);
+                    v = (pv[u][c] > lo) ? v : 0.f;                     // ReLU backward (lo = -inf without a ReLU: always true)
+                    if (ok[u]) { dpb[(size_t)c * vol + ee[u]] = v; acc0[c] += v; }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 27; ++k) wcur[k] = wnxt[k];
+        }
+    }
+    // ---- block partials (fixed order): MODE 0 -> part[((g*C+c)*chunks + chunk)*2 + {0,1}];  MODE 1 -> csum_part[(g*C+c)*chunks + chunk]
+    __shared__ double red[2][FT_MAXC][BN_THREADS / VG_WAVE];
+    const int chunks = a.per_group * a.tilesD;
+    const int chunk = (n % a.per_group) * a.tilesD + td;
+#pragma unroll
+    for (int c = 0; c < (CT ? CT : FT_MAXC); ++c) {
+        if (c >= C) continue;
+        const double s0 = wave_sum((double)acc0[c]);
+        const double s1 = MODE == 0 ? wave_sum((double)acc1[c]) : 0.0;
+        if (lane == 0) { red[0][c][wave] = s0; red[1][c][wave] = s1; }
+    }
+    __syncthreads();
+    if (tid < C) {
+        double s0 = 0, s1 = 0;
+        for (int wv = 0; wv < BN_THREADS / VG_WAVE; ++wv) { s0 += red[0][tid][wv]; s1 += red[1][tid][wv]; }
+        const size_t gc = (size_t)g * C + tid;
+        if (MODE == 0) { part[(gc * chunks + chunk) * 2] = s0; part[(gc * chunks + chunk) * 2 + 1] = s1; }
+        else if (csum_part) csum_part[gc * chunks + chunk] = s0;
+    }
+}
+
+static int ft_setup(const char* who, const float* dy, const float* w, const float* p, int N, int C, int ID, int IH, int IW, int per_group,
+                    FtParams* a, size_t* shmem) {
+    if (!dy || !w || !p || N <= 0 || C <= 0 || C > FT_MAXC || ID <= 0 || IH <= 0 || IW <= 0 || per_group <= 0 || N % per_group || N > 65535) {
+        vg_set_error("%s: bad arguments N=%d C=%d p=%dx%dx%d per_group=%d", who, N, C, ID, IH, IW, per_group); return VG_ERR_ARG;
+    }
+    a->N = N; a->C = C; a->ID = ID; a->IH = IH; a->IW = IW; a->per_group = per_group; a->relu = 0;
+    a->tilesD = vg_cdiv(ID, FT_TD);
+    a->inv_iw = 1.0f / (float)IW; a->inv_plane = 1.0f / (float)(IH * IW);
+    *shmem = (size_t)(FT_TD + 2) * (IH + 2) * (IW + 2) * sizeof(float) + 256;
+    if (*shmem > 150 * 1024) { vg_set_error("%s: a %dx%d dy plane tile does not fit LDS", who, IH + 2, IW + 2); return VG_ERR_UNSUPPORTED; }
+    if ((long long)FT_TD * IH * IW >= (1 << 22)) { vg_set_error("%s: tile too large for the position decode", who); return VG_ERR_UNSUPPORTED; }
+    return VG_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t vg_bn_tconv1_ws_bytes(int32_t N, int32_t C, int32_t ID, int32_t per_group) {
+    if (N <= 0 || C <= 0 || ID <= 0 || per_group <= 0 || N % per_group) return -1;
+    const int64_t chunks = (int64_t)per_group * vg_cdiv(ID, FT_TD);
+    return (int64_t)(N / per_group) * C * chunks * 2 * (int64_t)sizeof(double);
+}
+
+extern "C" int vg_bn_bwd_reduce_tconv1(const float* dy, const float* w, const float* p, int32_t N, int32_t C, int32_t ID, int32_t IH,
+                                       int32_t IW, int32_t per_group, int32_t relu, const float* mean, const float* rstd, void* ws,
+                                       double* sums, void* stream) {
+    FtParams a; size_t shmem;
+    int rc = ft_setup("vg_bn_bwd_reduce_tconv1", dy, w, p, N, C, ID, IH, IW, per_group, &a, &shmem);
+    if (rc) return rc;
+    if (!mean || !rstd || !ws || !sums) { vg_set_error("vg_bn_bwd_reduce_tconv1: null argument"); return VG_ERR_ARG; }
+    a.relu = relu;
+    hipStream_t s = (hipStream_t)stream;
+    const int G = N / per_group, chunks = per_group * a.tilesD;
+    double* part = (double*)ws;
+    if (C == 8)
+        vg_launch(bn_tconv1_k<0, 8>, dim3(a.tilesD, N), dim3(BN_THREADS), shmem, s, dy, w, p, (float*)nullptr, (const float*)nullptr, mean, rstd,
+                  (const double*)nullptr, 1.0, a, part, (double*)nullptr);
+    else
+        vg_launch(bn_tconv1_k<0, 0>, dim3(a.tilesD, N), dim3(BN_THREADS), shmem, s, dy, w, p, (float*)nullptr, (const float*)nullptr, mean, rstd,
+                  (const double*)nullptr, 1.0, a, part, (double*)nullptr);
+    if ((rc = vg_check_launch("bn_bwd_reduce_tconv1"))) return rc;
+    vg_launch(bn_fold_k, dim3(G * C), dim3(64), 0, s, (const double*)part, G * C, chunks, (double)per_group * ID * IH * IW, 2, sums);
+    return vg_check_launch("bn_bwd_reduce_tconv1 fold");
+}
+
+extern "C" int vg_bn_bwd_apply_tconv1(const float* dy, const float* w, const float* p, float* dp, int32_t N, int32_t C, int32_t ID,
+                                      int32_t IH, int32_t IW, int32_t per_group, int32_t relu, const float* gamma, const float* mean,
+                                      const float* rstd, const double* sums, double count, void* ws, float* chsum,
+                                      int32_t chsum_accumulate, void* stream) {
+    FtParams a; size_t shmem;
+    int rc = ft_setup("vg_bn_bwd_apply_tconv1", dy, w, p, N, C, ID, IH, IW, per_group, &a, &shmem);
+    if (rc) return rc;
+    if (!dp || !mean || !rstd || !sums || !(count > 0) || (chsum && !ws)) { vg_set_error("vg_bn_bwd_apply_tconv1: bad argument"); return VG_ERR_ARG; }
+    a.relu = relu;
+    hipStream_t s = (hipStream_t)stream;
+    const int G = N / per_group, chunks = per_group * a.tilesD;
+    double* csum_part = chsum ? (double*)ws : nullptr;
+    if (C == 8)
+        vg_launch(bn_tconv1_k<1, 8>, dim3(a.tilesD, N), dim3(BN_THREADS), shmem, s, dy, w, p, dp, gamma, mean, rstd, sums, count, a,
+                  (double*)nullptr, csum_part);
+    else
+        vg_launch(bn_tconv1_k<1, 0>, dim3(a.tilesD, N), dim3(BN_THREADS), shmem, s, dy, w, p, dp, gamma, mean, rstd, sums, count, a,
+                  (double*)nullptr, csum_part);
+    if ((rc = vg_check_launch("bn_bwd_apply_tconv1"))) return rc;
+    if (chsum) {
+        vg_launch(csum_fold_k, dim3(C), dim3(64), 0, s, (const double*)csum_part, G, (int)C, chunks, (int)chsum_accumulate, chsum);
+        return vg_check_launch("bn_bwd_apply_tconv1 csum_fold");
+    }
+    return VG_OK;
+}
+
+namespace {
 __global__ void __launch_bounds__(64)
 chsum_fold_k(const double* __restrict__ part, int C, int chunks, int accumulate, float* __restrict__ out) {
     const int c = blockIdx.x, lane = threadIdx.x;

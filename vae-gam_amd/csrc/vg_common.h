@@ -130,4 +130,10 @@ __device__ __forceinline__ void vg_mfma16(float a, float b, vg_f32x4& acc) {
 }
 #endif
 
+// two adjacent floats as ONE 8-byte store at a 4-byte-aligned address (rows of odd pitch start on odd dwords): gfx950 runs global
+// accesses in unaligned mode, so the under-aligned dwordx2 is legal; two strided dword stores per lane instead leave every
+// 64-byte line half-written by each instruction (measured as 1.9x write amplification on the stride-2 transposed conv)
+struct __attribute__((packed, aligned(4))) vg_f2u { float a, b; };
+__device__ __forceinline__ void vg_store2(float* p, float a, float b) { vg_f2u v; v.a = a; v.b = b; *reinterpret_cast<vg_f2u*>(p) = v; }
+
 __host__ __device__ static inline int vg_cdiv(int a, int b) { return (a + b - 1) / b; }

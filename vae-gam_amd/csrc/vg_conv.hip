@@ -806,16 +806,22 @@ tconv3d_s2_k(const float* __restrict__ x, const float* __restrict__ wpk, const f
             for (int co = 0; co < COT; ++co) {
                 const float bv = bias ? bias[co0 + co] : 0.f;
                 const size_t base = (((size_t)n * CO + co0 + co) * d.OD + od) * plane + (size_t)oh * d.OW;
+                // the thread's two outputs along w are adjacent: one 8-byte store per (row, channel) where both exist
+                const int ow0 = 2 * jw - d.pad_w;
+                float o2[2];
 #pragma unroll
                 for (int rw = 0; rw < 2; ++rw) {
-                    const int ow = 2 * jw + rw - d.pad_w;
-                    if (ow >= 0 && ow < d.OW) {
-                        const float v = acc[rd][rh][rw][co];
-                        const float o = (v == -__builtin_inff()) ? 0.f : v + bv;
-                        y[base + ow] = o;
-                        const float h = stats_relu ? vg_max(o, 0.f) : o;
+                    const float v = acc[rd][rh][rw][co];
+                    o2[rw] = (v == -__builtin_inff()) ? 0.f : v + bv;
+                    if (ow0 + rw >= 0 && ow0 + rw < d.OW) {
+                        const float h = stats_relu ? vg_max(o2[rw], 0.f) : o2[rw];
                         st_s[co] += h; st_q[co] = fmaf(h, h, st_q[co]);
                     }
+                }
+                if (ow0 >= 0 && ow0 + 1 < d.OW) vg_store2(y + base + ow0, o2[0], o2[1]);
+                else {
+                    if (ow0 >= 0 && ow0 < d.OW) y[base + ow0] = o2[0];
+                    if (ow0 + 1 >= 0 && ow0 + 1 < d.OW) y[base + ow0 + 1] = o2[1];
                 }
             }
         }

@@ -61,6 +61,7 @@ def _call(t, fn, *args):
 # overlap and the extra stream joins only add boundaries.  Left off; kept because it may pay at smaller batches.
 import os as _os
 SIDE_STREAM = bool(int(_os.environ.get('VG_SIDE_STREAM', '0')))
+FUSE_LAST_BN_BWD = bool(int(_os.environ.get('VG_FUSE_LAST_BN_BWD', '1')))     # bnt5 backward + convt5 data gradient in two fused passes
 FC_SIDE_STREAM = bool(int(_os.environ.get('VG_FC_SIDE_STREAM', '0')))     # fully connected dW/db on the second stream: measured 4.41 vs 4.28 ms/step (worse), off
 _SIDE = {}
 
@@ -383,6 +384,43 @@ def bn_backward_(dxe, p, gamma, mean, rstd, relu, per_group, sync=None, beta=Non
     return dg, db
 
 
+def bn_backward_tconv1(dy, weight, p, gamma, mean, rstd, relu, per_group, sync=None, beta=None, producer_bias_grad=None):
+    """Batch-norm backward fused with the data gradient of the ONE-output-channel 3x3x3 stride-1 transposed conv behind it
+    (the decoder's last stage): dy [N][1][D+2][H+2][W+2], weight [C][1][3][3][3], p [N][C][D][H][W] -> dp (new tensor).
+    The C-channel gradient w.r.t. the normalised tensor is recomputed from dy in both passes and never stored.
+    Returns (dp, dgamma, dbeta) with the same conventions as bn_backward_."""
+    lib = _lib.get_lib()
+    N, C = p.shape[0], p.shape[1]
+    ID, IH, IW = p.shape[2:]
+    assert tuple(dy.shape) == (N, 1, ID + 2, IH + 2, IW + 2) and tuple(weight.shape) == (C, 1, 3, 3, 3)
+    _chk(dy); _chk(p)
+    w = _chk(weight.detach().contiguous())
+    G = N // per_group
+    P = ID * IH * IW
+    ws = torch.empty(lib.size('vg_bn_tconv1_ws_bytes', N, C, ID, per_group) // 8, dtype=torch.float64, device=p.device)
+    sums = torch.empty((G * C, 2), dtype=torch.float64, device=p.device)
+    _call(p, 'vg_bn_bwd_reduce_tconv1', _p(dy), _p(w), _p(p), N, C, ID, IH, IW, per_group, int(relu), _p(mean), _p(rstd), _p(ws), _p(sums))
+    count = float(per_group * P)
+    local = None
+    if sync is not None:
+        local = sums.clone()
+        sums = sync(sums)
+        count = count * sync.world_size
+    dp = torch.empty_like(p)
+    if producer_bias_grad is not None:
+        assert producer_bias_grad.shape == (C,) and producer_bias_grad.is_contiguous() and producer_bias_grad.dtype == torch.float32
+    _call(p, 'vg_bn_bwd_apply_tconv1', _p(dy), _p(w), _p(p), _p(dp), N, C, ID, IH, IW, per_group, int(relu), _p(gamma), _p(mean), _p(rstd),
+          _p(sums), count, _p(ws), _p(producer_bias_grad), 1)
+    src = local if local is not None else sums
+    gg, bg = _grad_buf(gamma), _grad_buf(beta)
+    if gg is not None and bg is not None:
+        _call(p, 'vg_bn_param_grad', _p(src), G, C, _p(gg), _p(bg), 1)
+        return dp, None, None
+    dg = torch.empty(C, dtype=torch.float32, device=p.device); db = torch.empty_like(dg)
+    _call(p, 'vg_bn_param_grad', _p(src), G, C, _p(dg), _p(db), 0)
+    return dp, dg, db
+
+
 def channel_sum(x, out=None):
     lib = _lib.get_lib()
     N, C = x.shape[0], x.shape[1]
@@ -492,14 +530,19 @@ class BnConvAct(torch.autograd.Function):
         wb = ctx.packed.get(spec.name, 'bwd') if ctx.packed is not None else pack_weight(weight, spec, 'bwd')
         in_size = tuple(p_in.shape[2:])
         if ctx.has_bn:
-            dp = conv_backward_data(dy, wb, spec, in_size, None)
             pbg = None
             if ctx.producer_bias is not None:
                 pb = ctx.producer_bias
                 if pb.grad is None:
                     pb.grad = torch.zeros_like(pb)
                 pbg = pb.grad
-            dgamma, dbeta = bn_backward_(dp, p_in, gamma, mean, rstd, relu_in, per_group, ctx.sync, beta, pbg)
+            if FUSE_LAST_BN_BWD and spec.kind == 'convt' and spec.stride == 1 and spec.co == 1 and tuple(spec.k) == (3, 3, 3) \
+                    and tuple(spec.pad) == (0, 0, 0) and spec.ci <= 16:
+                # last decoder stage: the data gradient is recomputed inside the batch-norm backward passes, never stored
+                dp, dgamma, dbeta = bn_backward_tconv1(dy, weight, p_in, gamma, mean, rstd, relu_in, per_group, ctx.sync, beta, pbg)
+            else:
+                dp = conv_backward_data(dy, wb, spec, in_size, None)
+                dgamma, dbeta = bn_backward_(dp, p_in, gamma, mean, rstd, relu_in, per_group, ctx.sync, beta, pbg)
         else:
             dp = conv_backward_data(dy, wb, spec, in_size, p_in if relu_in else None)
         return dp, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
