@@ -61,6 +61,35 @@ int vg_tconv3d_s2_stats(const vg_conv_desc* d, const float* x, const float* wpk,
                         const float* in_scale, const float* in_shift, float* y, int32_t stats_per_group,
                         int32_t stats_relu, double* stats_part, void* stream);
 
+/* Table-driven implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32): the forward passes and
+ * data gradients of the conv / transposed-conv layers with 8 or 16 output channels (vae_reg_GP.py:189-215; replaces F.conv3d /
+ * F.conv_transpose3d and their autograd data gradients, like vg_corr3d / vg_tconv3d_s2, for the launches that are real contractions).
+ * The host describes the layer as a position grid + window-offset tables (vae_gam_amd/ops.py: mm_plan):
+ *   16 matrix rows = (16 / CO) replicas x CO output channels;  columns = 16 consecutive positions (pd, ph, pw) of a block's grid of
+ *   PD x PH x PW positions;  class q (1 for correlations, the (rd, rh) output parities of a stride-2 transposed conv) contributes
+ *   ks[q] k-steps of 4 window offsets per input channel.
+ *   a_img [sum_q CI*ks[q]][64]: A operands, lane l = row (l & 15), offset 4*step + (l >> 4)  -- gathered from the weights by vg_gather_f32;
+ *   tau   [sum_q ks[q]][4] int32: the window offset dd*IH*IW + dh*IW + dw of (step, kk);  dlt [sum_q ks[q]][4][3] int32: (dd, dh, dw).
+ *   position (pd, ph, pw) reads input element (pd*sdi + dd, ph*shi + dh, pw*swi + dw) (zero outside the tensor) and writes output
+ *   (pd*sdo + od0[q], ph*sho + oh0[q], pw*swo + ow0[q] + replica).
+ *   Block b of a sample stages input planes [b*PD*sdi + d0, + LD) of cc channels at a time (flat LDS-DMA, double-buffered).
+ * bias / in_scale / in_shift / mask_src / stats_*: as vg_corr3d / vg_tconv3d_s2_stats (stats chunks: vg_conv_mm_stats_chunks). */
+typedef struct vg_mm_desc {
+    int32_t N, CI, CO;
+    int32_t ID, IH, IW, OD, OH, OW;
+    int32_t nq, ks[4];
+    int32_t PDT, PH, PW, PD;
+    int32_t sdi, shi, swi, d0, LD, cc;
+    int32_t sdo, sho, swo, od0[4], oh0[4], ow0[4];
+    int32_t relu_in, per_group, tpc, slack;
+} vg_mm_desc;
+int64_t vg_conv_mm_stats_chunks(const vg_mm_desc* d, int32_t stats_per_group);
+int vg_conv_mm(const vg_mm_desc* d, const float* x, const float* a_img, const int32_t* tau, const int32_t* dlt, const float* bias,
+               const float* in_scale, const float* in_shift, const float* mask_src, float* y, int32_t stats_per_group,
+               int32_t stats_relu, double* stats_part, void* stream);
+/* dst[e] = idx[e] >= 0 ? src[idx[e]] : 0  -- builds every layer's A image from the flat fp32 parameter buffer in one launch per step */
+int vg_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, void* stream);
+
 /* weight gradient:  dw[cb][ca][k] = sum_{n,p} PB(b)[n][cb][p] * PA(a)[n][ca][p*stride + k - pad]
  * b: [N][CB][PD][PH][PW], a: [N][CA][AD][AH][AW] (zero outside).  For a Conv3d layer b = dy,
  * a = layer input (prologue on a); for a ConvTranspose3d layer b = layer input (prologue on b),

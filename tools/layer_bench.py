@@ -40,11 +40,24 @@ for specs, sizes, N in ((geom.enc, geom.enc_sizes(), B), (geom.dec, geom.dec_siz
         wf = ops.pack_weight(w, sp, 'fwd'); wb = ops.pack_weight(w, sp, 'bwd')
         y = ops.conv_forward(x, wf, b, sp, True, sc, sh, B)
         dy = torch.randn_like(y)
-        t_f = timeit(lambda: ops.conv_forward(x, wf, b, sp, True, sc, sh, B))
-        t_b = timeit(lambda: ops.conv_backward_data(dy, wb, sp, sizes[i], x)) if sp.name != 'conv1' else 0.0
+        mmf = ops._mm_for(None, w, sp, 'fwd', sizes[i], None)           # matrix-core kernel where a plan exists (VG_CONV_MM=0: off)
+        mmb = ops._mm_for(None, w, sp, 'bwd', sizes[i + 1], sizes[i]) if sp.name != 'conv1' else None
+        if mmf is not None:
+            ym = ops.conv_mm(x, mmf[0], mmf[1], b, True, sc, sh, B)
+            assert float((ym - y).abs().max()) <= 1e-3 * float(y.abs().max()), sp.name
+            t_f = timeit(lambda: ops.conv_mm(x, mmf[0], mmf[1], b, True, sc, sh, B))
+        else:
+            t_f = timeit(lambda: ops.conv_forward(x, wf, b, sp, True, sc, sh, B))
+        if sp.name == 'conv1':
+            t_b = 0.0
+        elif mmb is not None:
+            t_b = timeit(lambda: ops.conv_mm(dy, mmb[0], mmb[1], None, False, None, None, 1, x))
+        else:
+            t_b = timeit(lambda: ops.conv_backward_data(dy, wb, sp, sizes[i], x))
+        tag = ('M' if mmf is not None else '-') + ('M' if mmb is not None else '-')
         t_w = timeit(lambda: ops.conv_weight_grad(x, dy, sp, True, sc, sh, B))
         macs = N * sp.co * sp.ci * int(np.prod(sp.k)) * int(np.prod(sizes[i + 1] if sp.kind == 'conv' else sizes[i]))
         gf = 2 * macs / 1e9
         tot['fwd'] += t_f; tot['bwd'] += t_b; tot['wgrad'] += t_w
-        print('%-8s %10.1f %10.1f %10.1f   %8.2f  %6.2f TF/s' % (sp.name, t_f, t_b, t_w, gf, gf / max(t_f, t_b, t_w) * 1e-3 * 1e3 / 1e3 * 1e3 / 1e3 if False else gf / (max(t_f, t_b, t_w) * 1e-6) / 1e3))
+        print('%-8s %10.1f %10.1f %10.1f   %8.2f  %6.2f TF/s  %s' % (sp.name, t_f, t_b, t_w, gf, gf / max(t_f, t_b, t_w) * 1e-3 * 1e3 / 1e3 * 1e3 / 1e3 if False else gf / (max(t_f, t_b, t_w) * 1e-6) / 1e3, tag))
 print('total us: fwd %.0f  bwd-data %.0f  wgrad %.0f  sum %.0f' % (tot['fwd'], tot['bwd'], tot['wgrad'], sum(tot.values())))

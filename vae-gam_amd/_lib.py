@@ -28,6 +28,12 @@ class WgradDesc(ctypes.Structure):
                                    'stride', 'pad_d', 'pad_h', 'pad_w', 'pro_on_a', 'relu_in', 'per_group')]
 
 
+class MmDesc(ctypes.Structure):
+    _fields_ = [(n, i32) for n in ('N', 'CI', 'CO', 'ID', 'IH', 'IW', 'OD', 'OH', 'OW', 'nq')] + [('ks', i32 * 4)] + \
+               [(n, i32) for n in ('PDT', 'PH', 'PW', 'PD', 'sdi', 'shi', 'swi', 'd0', 'LD', 'cc', 'sdo', 'sho', 'swo')] + \
+               [('od0', i32 * 4), ('oh0', i32 * 4), ('ow0', i32 * 4)] + [(n, i32) for n in ('relu_in', 'per_group', 'tpc', 'slack')]
+
+
 class GainDesc(ctypes.Structure):
     _fields_ = [('C', i32), ('B', i32), ('n', i32), ('hrf_taps', i32), ('jitter_b', f64), ('jitter_ku', f64), ('prior_var', f64)]
 
@@ -61,6 +67,9 @@ _PROTOS = {
     'vg_gam_elbo_bwd': (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, vp]),
     'vg_pack_weights': (ctypes.c_int, [vp, vp, vp, i32, i64, vp]),
     'vg_cholesky_f64': (ctypes.c_int, [vp, vp, i32, i32, vp]),
+    'vg_conv_mm_stats_chunks': (i64, [ctypes.POINTER(MmDesc), i32]),
+    'vg_conv_mm': (ctypes.c_int, [ctypes.POINTER(MmDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+    'vg_gather_f32': (ctypes.c_int, [vp, vp, vp, i64, vp]),
     'vg_gp_gain_ws_bytes': (i64, [i32, i32, i32]),
     'vg_gp_gain_fwd': (ctypes.c_int, [ctypes.POINTER(GainDesc), vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'vg_gp_gain_bwd': (ctypes.c_int, [ctypes.POINTER(GainDesc), vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]),

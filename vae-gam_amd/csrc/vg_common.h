@@ -136,4 +136,19 @@ __device__ __forceinline__ void vg_mfma16(float a, float b, vg_f32x4& acc) {
 struct __attribute__((packed, aligned(4))) vg_f2u { float a, b; };
 __device__ __forceinline__ void vg_store2(float* p, float a, float b) { vg_f2u v; v.a = a; v.b = b; *reinterpret_cast<vg_f2u*>(p) = v; }
 
+// a value the optimiser may not see through, pinned to a vector register (it would turn 0/1 factors and all-ones/zero masks back into
+// boolean predicates, i.e. scalar register pairs)
+#ifdef VG_EMU
+static inline float vg_opaque(float v) { return v; }
+static inline unsigned vg_opaque(unsigned v) { return v; }
+#else
+__device__ __forceinline__ float vg_opaque(float v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ unsigned vg_opaque(unsigned v) { asm volatile("" : "+v"(v)); return v; }
+#endif
+
+// value with its bits and-ed by an all-ones / all-zero mask: an exact select that keeps its condition in a VECTOR register
+__host__ __device__ static inline float vg_and(float v, unsigned m) {
+    union { float f; unsigned u; } t; t.f = v; t.u &= m; return t.f;
+}
+
 __host__ __device__ static inline int vg_cdiv(int a, int b) { return (a + b - 1) / b; }

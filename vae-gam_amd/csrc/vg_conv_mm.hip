@@ -1,0 +1,371 @@
+// vg_conv_mm.hip -- table-driven implicit-GEMM convolution on the fp32 matrix cores (gfx950, v_mfma_f32_16x16x4_f32: exact fp32).
+//
+// One kernel for the conv / transposed-conv forward passes and data gradients of vae_reg_GP.py:189-215 whose channel counts make
+// them real contractions (8 or 16 output channels): D[row][pos] += sum_kappa A[row][kappa] * B[kappa][pos] with
+//   rows  = 16 = (16 / CO) "replicas" x CO output channels.  With 8 output channels the upper 8 rows compute the NEXT output
+//           column from the same B operand (Toeplitz pair: their weights are shifted by one column / one stride), so no matrix
+//           row idles;
+//   pos   = 16 consecutive positions of a block's position grid (PD planes x all rows x all columns of the layer);
+//   kappa = (input channel, window offset): the window offsets of every k-step come from a TABLE built on the host
+//           (ops.mm_plan): strided correlations (window = kernel, plus the replica shift), stride-2 transposed convolutions in
+//           gather form (one "class" per output parity (rd, rh), window = the taps of that parity), padded or not, share it.
+// A operand: a [class][ci][k-step][64 lanes] image of the layer's weights (zeros where a row has no weight for that offset),
+//   gathered from the flat parameter buffer once per step (vg_gather_f32), copied to LDS once per (persistent) block.
+// B operand: ONE ds_read_b32 per MFMA at (position base + table offset) out of the input planes the block needs, which are
+//   whole planes of the tensor = one contiguous span per channel, copied flat into LDS by LDS-DMA (no halo cells, no per-row
+//   address arithmetic), double-buffered over (sample, channel chunk) behind the matrix work.  Zero padding / tile overhang:
+//   a per-lane bit mask per accumulator tile (bit s = "the element k-step s reads exists"), built once per block.
+//   The producer's ReLU / batch-norm affine is applied once per staged element, in place, by the thread that copied it.
+// Blocks are persistent over samples: masks, position offsets, the A image and the offset table are set up once.
+#include "vg_common.h"
+#include <stdlib.h>
+#include "../../include/vaegam.h"
+
+namespace {
+
+constexpr int MM_T = 512;                  // 8 wavefronts: two per SIMD.  (Measured alternative: 4-wave workgroups, 2-3 per CU, single-buffered
+constexpr int MM_W = MM_T / VG_WAVE;       // input -- twice the tiles per wave, fewer planes per block, more re-staging: 1.3-1.7x slower.)
+constexpr int MM_MAXQ = 4;
+constexpr int MM_ZPAD = 64;                // zero floats at the head of every channel slot: where B operands that do not exist are read from
+
+struct MmParams {
+    vg_mm_desc d;
+    int bps, nsplit;                       // blocks per sample, sample splits (grid = bps * nsplit)
+    int ksbase[MM_MAXQ], a_off[MM_MAXQ];   // first table row / first A-image float of class q
+    int kstot, aimg_floats;
+    int a_res;                             // 1: the whole A image stays in LDS; 0: the slices of the running channel chunk are staged with it
+    int CHP, buf_floats;                   // channel pitch, floats of the input buffer
+    int tau_off, in_off;                   // LDS float offsets
+    int has_pro;
+};
+
+template <int V> struct mm_int { static constexpr int value = V; };
+// f(mm_int<n>) for the run-time n in [1, MAXN]
+template <int MAXN, typename F>
+__device__ __forceinline__ void mm_dispatch(int n, F&& f) {
+    if constexpr (MAXN >= 1) {
+        if (n == MAXN) { f(mm_int<MAXN>{}); return; }
+        mm_dispatch<MAXN - 1>(n, f);
+    }
+}
+// f(mm_int<0>) ... f(mm_int<N-1>)
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void mm_static_for(F&& f) {
+    if constexpr (I < N) { f(mm_int<I>{}); mm_static_for<N, I + 1>(f); }
+}
+
+// K0..K3: k-steps per input channel of class 0..3 as compile-time constants (0 = read them from the descriptor: generic, slower).
+// With them the k-step loop unrolls into straight-line code, the LDS offset of every (tile, step) operand lives in a register and
+// every LDS read of a channel is issued ahead of the matrix instructions that consume it (a run-time loop pays two dependent LDS
+// latencies per step).  Classes (NQ = 4: the output parities of a stride-2 transposed conv) are processed one after the other on
+// the same staged input, each stored as soon as it is finished: its stores drain behind the next class's matrix work.
+template <int NQ, int TPC, int K0, int K1, int K2, int K3>
+__global__ void __launch_bounds__(MM_T)
+conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const int* __restrict__ tau, const int* __restrict__ dlt,
+          const float* __restrict__ bias, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+          const float* __restrict__ mask_src, float* __restrict__ y, double* __restrict__ stats_part, int stats_pg, int stats_relu,
+          MmParams p) {
+    VG_DYN_SMEM(float, lds);
+    const vg_mm_desc& d = p.d;
+    float* Al = lds;
+    int* Tl = reinterpret_cast<int*>(lds + p.tau_off);
+    float* In = lds + p.in_off;
+    const int tid = threadIdx.x, lane = tid % VG_WAVE, wave = vg_wave_id();
+    const int kk = lane >> 4, jl = lane & 15;
+    const int b = blockIdx.x % p.bps, split = blockIdx.x / p.bps;
+    const int IHW = d.IH * d.IW, OHW = d.OH * d.OW;
+    const int CI = d.CI, CO = d.CO;
+    constexpr bool STATIC_K = K0 > 0;
+    constexpr int KSUM = K0 + K1 + K2 + K3;
+
+    for (int i = tid; i < p.aimg_floats; i += MM_T) Al[i] = a_img[i];
+    if (!STATIC_K) for (int i = tid; i < p.kstot * 64; i += MM_T) Tl[i] = tau[(i >> 6) * 4 + ((i & 63) >> 4)];
+    for (int i = tid; i < 2 * d.cc * MM_ZPAD; i += MM_T) In[(i / MM_ZPAD) * p.CHP + (i % MM_ZPAD)] = 0.f;  // the zero pads of both buffers (never written again)
+
+    // ---- geometry of this block (the same for every sample it visits)
+    const int pd0 = b * d.PD;
+    const int npd = min(d.PD, d.PDT - pd0);
+    const int npos = npd * d.PH * d.PW;
+    const int ntiles = (npos + 15) / 16;
+    const int dlo = pd0 * d.sdi + d.d0;                                  // first staged input plane (may lie outside the tensor)
+    const int pl_lo = max(dlo, 0), pl_hi = min(dlo + d.LD, d.ID);
+    const int nfl = max(pl_hi - pl_lo, 0) * IHW;                         // floats to copy per channel
+    const int dst0 = (pl_lo - dlo) * IHW;
+    // Per accumulator tile and k-step: WHERE this lane's B operand sits inside a channel slot -- the element (pd*sdi + dd, ph*shi + dh,
+    // pw*swi + dw) of the staged planes, or, where that element does not exist (zero padding, tile overhang, lanes past the last
+    // position), the slot's zero pad.  Float offsets from the slot base; with compile-time step counts they live in registers
+    // (pt), so a matrix instruction costs one address add + one ds_read_b32 and no select.
+    int pcoord[TPC];
+    int pt[TPC][STATIC_K ? KSUM : 1];
+    int posBase[TPC]; unsigned vm[NQ][TPC];                              // run-time step counts only
+#pragma unroll
+    for (int i = 0; i < TPC; ++i) {
+        const int pf = (i * MM_W + wave) * 16 + jl;
+        const bool pv = pf < npos;
+        const int pfc = pv ? pf : 0;
+        const int pdl = pfc / (d.PH * d.PW), r2 = pfc - pdl * (d.PH * d.PW);
+        const int ph = r2 / d.PW, pw = r2 - ph * d.PW;
+        pcoord[i] = pv ? ((pdl << 20) | (ph << 10) | pw) : -1;
+        const int pb = (pdl * d.sdi - d.d0) * IHW + ph * d.shi * d.IW + pw * d.swi;
+        posBase[i] = pb;
+        if constexpr (STATIC_K) {
+#pragma unroll
+            for (int sg = 0; sg < KSUM; ++sg) {                          // sg = table row (classes back to back)
+                const int* e = dlt + (sg * 4 + kk) * 3;
+                const int id = (pd0 + pdl) * d.sdi + e[0], ih = ph * d.shi + e[1], iw = pw * d.swi + e[2];
+                const bool ok = pv && id >= 0 && id < d.ID && ih >= 0 && ih < d.IH && iw >= 0 && iw < d.IW;
+                pt[i][sg] = ok ? MM_ZPAD + pb + tau[sg * 4 + kk] : 0;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                unsigned m = 0;
+                for (int s = 0; s < d.ks[q]; ++s) {
+                    const int* e = dlt + ((p.ksbase[q] + s) * 4 + kk) * 3;
+                    const int id = (pd0 + pdl) * d.sdi + e[0], ih = ph * d.shi + e[1], iw = pw * d.swi + e[2];
+                    const bool ok = pv && id >= 0 && id < d.ID && ih >= 0 && ih < d.IH && iw >= 0 && iw < d.IW;
+                    m |= (ok ? 1u : 0u) << s;
+                }
+                vm[q][i] = m;
+            }
+        }
+    }
+    const float lo = d.relu_in ? 0.f : -__builtin_inff();
+    const size_t vol = (size_t)IHW * d.ID, ovol = (size_t)OHW * d.OD;
+    const int nchunks = (CI + d.cc - 1) / d.cc;
+    const int nsamp = (d.N - split + p.nsplit - 1) / p.nsplit;          // samples this block visits: split, split + nsplit, ...
+    const int units = nsamp * nchunks;
+
+    vg_f32x4 acc[TPC];
+    float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
+    // rows 4*kk .. 4*kk+3 of a tile: replica and first channel are lane constants
+    const int rho_l = (CO == 8) ? (kk >> 1) : 0;
+    const int co_l = (CO == 8) ? ((kk & 1) * 4) : kk * 4;
+    float bias_l[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias_l[r] = bias ? bias[co_l + r] : 0.f;
+    int nact = 0;                                                        // tiles this wave owns (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < TPC; ++i) nact += (i * MM_W + wave < ntiles) ? 1 : 0;
+
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TPC; ++i) { acc[i].v[0] = 0.f; acc[i].v[1] = 0.f; acc[i].v[2] = 0.f; acc[i].v[3] = 0.f; }
+    };
+    // store class q of sample n from the accumulators: lane owns position jl of each tile, rows 4*kk .. 4*kk+3
+    auto store_class = [&](int n, int q) __attribute__((always_inline)) {
+        float* yn = y + (size_t)n * CO * ovol;
+        const float* mn = mask_src ? mask_src + (size_t)n * CO * ovol : nullptr;
+        const int od0 = d.od0[q], oh0 = d.oh0[q], ow0 = d.ow0[q] + rho_l;
+#pragma unroll
+        for (int i = 0; i < TPC; ++i) {
+            if (i >= nact || pcoord[i] < 0) continue;
+            const int pdl = pcoord[i] >> 20, ph = (pcoord[i] >> 10) & 1023, pw = pcoord[i] & 1023;
+            const int od = (pd0 + pdl) * d.sdo + od0, oh = ph * d.sho + oh0, ow = pw * d.swo + ow0;
+            if (od < 0 || od >= d.OD || oh < 0 || oh >= d.OH || ow < 0 || ow >= d.OW) continue;
+            const int sp = od * OHW + oh * d.OW + ow;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int idx = sp + (co_l + r) * (int)ovol;              // < 2^31: one sample of one layer
+                float v = acc[i].v[r] + bias_l[r];
+                if (mn) v = (mn[idx] > 0.f) ? v : 0.f;
+                yn[idx] = v;
+                const float h = stats_relu ? vg_max(v, 0.f) : v;
+                st_s[r] += h; st_q[r] = fmaf(h, h, st_q[r]);
+            }
+        }
+    };
+    auto flush_stats = [&](int n) __attribute__((always_inline)) {
+        // per wavefront and sample: [sum, sum of squares] of relu?(y) per channel, laid out for vg_bn_stats_from_parts
+        const int g = n / stats_pg;
+        const size_t chunks = (size_t)stats_pg * p.bps * MM_W;
+        const size_t chunkid = ((size_t)(n % stats_pg) * p.bps + b) * MM_W + wave;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float sa = st_s[r], sb = st_q[r];
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) { sa += __shfl_xor(sa, off); sb += __shfl_xor(sb, off); }
+            if (CO == 8) { sa += __shfl_xor(sa, 32); sb += __shfl_xor(sb, 32); }   // the two replicas of a channel
+            if (jl == 0 && (CO == 16 || kk < 2)) {
+                double* dst = stats_part + (((size_t)g * CO + co_l + r) * chunks + chunkid) * 2;
+                dst[0] = (double)sa; dst[1] = (double)sb;
+            }
+            st_s[r] = 0.f; st_q[r] = 0.f;
+        }
+    };
+
+    // input planes of unit u (sample, channel chunk) -> buffer u & 1: one contiguous span per channel, flat LDS-DMA
+    auto stage = [&](int u) __attribute__((always_inline)) {
+        const int n = split + (u / nchunks) * p.nsplit, c0 = (u % nchunks) * d.cc;
+        const int cc = min(d.cc, CI - c0);
+        float* buf = In + (u & 1) * p.buf_floats;
+        const float* src0 = x + ((size_t)n * CI + c0) * vol + (size_t)pl_lo * IHW;
+        for (int c = 0; c < cc; ++c) {
+            const float* src = src0 + (size_t)c * vol;
+            float* dst = buf + c * p.CHP + MM_ZPAD + dst0;
+            for (int o = wave * VG_WAVE; o < nfl; o += MM_T)
+                if (o + lane < nfl) vg_dma4(src + o + lane, dst + o);
+        }
+    };
+    __syncthreads();
+    if (units > 0) stage(0);
+    for (int u = 0; u < units; ++u) {
+        const int n = split + (u / nchunks) * p.nsplit, chunk = u % nchunks, c0 = chunk * d.cc;
+        const int cc = min(d.cc, CI - c0);
+        float* cur = In + (u & 1) * p.buf_floats;
+        vg_dma_wait();                                                   // this thread's share of unit u has landed
+        if (p.has_pro) {
+            // ReLU / batch-norm affine once per staged element, by the thread that copied it (same loop shape as the copy)
+            const int g_aff = (in_scale != nullptr) ? n / d.per_group : 0;
+            for (int c = 0; c < cc; ++c) {
+                float sc = 1.f, sh = 0.f;
+                if (in_scale != nullptr) { sc = in_scale[g_aff * CI + c0 + c]; sh = in_shift[g_aff * CI + c0 + c]; }
+                float* dst = cur + c * p.CHP + MM_ZPAD + dst0;
+                for (int o = wave * VG_WAVE; o < nfl; o += MM_T)
+                    if (o + lane < nfl) dst[o + lane] = fmaf(vg_max(dst[o + lane], lo), sc, sh);
+            }
+        }
+        __syncthreads();                                                 // unit u complete in LDS; every wave is past unit u-1
+        if (u + 1 < units) stage(u + 1);                                 // into the buffer unit u-1 used: lands behind this unit's matrix work
+        // ---- matrix work.  The body is instantiated per number of tiles THIS wave owns (wave-uniform): no per-tile branches inside.
+        auto class_work = [&](auto qc, auto ntc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int NT = decltype(ntc)::value;
+            for (int c = 0; c < cc; ++c) {
+                const float* curc = cur + c * p.CHP;
+                if constexpr (STATIC_K) {
+                    constexpr int KSQ = q == 0 ? K0 : q == 1 ? K1 : q == 2 ? K2 : K3;
+                    constexpr int SG0 = q == 0 ? 0 : q == 1 ? K0 : q == 2 ? K0 + K1 : K0 + K1 + K2;
+                    const float* Aq = Al + p.a_off[q] + (c0 + c) * KSQ * 64 + lane;
+#pragma unroll
+                    for (int s = 0; s < KSQ; ++s) {
+                        const float aw = Aq[s * 64];
+                        float bv[NT];
+#pragma unroll
+                        for (int i = 0; i < NT; ++i) bv[i] = curc[pt[i][SG0 + s]];
+#pragma unroll
+                        for (int i = 0; i < NT; ++i) vg_mfma16(aw, bv[i], acc[i]);
+                    }
+                } else {
+                    const int ksq = d.ks[q];
+                    const float* Aq = Al + p.a_off[q] + (c0 + c) * ksq * 64 + lane;
+                    const int* Tq = Tl + p.ksbase[q] * 64 + lane;
+                    for (int s = 0; s < ksq; ++s) {
+                        const float aw = Aq[s * 64];
+                        const int off = Tq[s * 64] + MM_ZPAD;
+                        const unsigned bit = 1u << s;
+                        float bv[NT];
+#pragma unroll
+                        for (int i = 0; i < NT; ++i) bv[i] = curc[(vm[q][i] & bit) ? posBase[i] + off : 0];
+#pragma unroll
+                        for (int i = 0; i < NT; ++i) vg_mfma16(aw, bv[i], acc[i]);
+                    }
+                }
+            }
+        };
+        if constexpr (NQ == 1) {
+            if (chunk == 0) zero_acc();
+            if (nact > 0) mm_dispatch<TPC>(nact, [&](auto ntc) __attribute__((always_inline)) { class_work(mm_int<0>{}, ntc); });
+            if (chunk == nchunks - 1) {
+                store_class(n, 0);
+                if (stats_part) flush_stats(n);
+            }
+        } else {
+            // all channels are resident (the host plans one chunk per sample for multi-class layers)
+            mm_static_for<NQ>([&](auto qc) __attribute__((always_inline)) {
+                zero_acc();
+                if (nact > 0) mm_dispatch<TPC>(nact, [&](auto ntc) __attribute__((always_inline)) { class_work(qc, ntc); });
+                store_class(n, decltype(qc)::value);
+            });
+            if (stats_part) flush_stats(n);
+        }
+    }
+}
+
+}  // namespace
+
+static int mm_plan_params(const vg_mm_desc* d, MmParams* p, size_t* shmem, const char* who) {
+    if (!d || d->N <= 0 || d->CI <= 0 || (d->CO != 8 && d->CO != 16) || d->nq < 1 || d->nq > MM_MAXQ || d->PD <= 0 || d->PDT <= 0 ||
+        d->PH <= 0 || d->PW <= 0 || d->slack < 0 || d->PH > 1023 || d->PW > 1023 || d->PD > 1023 || d->cc <= 0 || d->LD <= 0 || d->tpc <= 0) {
+        vg_set_error("%s: bad descriptor", who); return VG_ERR_ARG;
+    }
+    p->d = *d;
+    p->bps = vg_cdiv(d->PDT, d->PD);
+    int ns = 256 / p->bps; if (ns < 1) ns = 1; if (ns > d->N) ns = d->N;
+    p->nsplit = ns;
+    int row = 0, af = 0;
+    for (int q = 0; q < d->nq; ++q) {
+        if (d->ks[q] <= 0 || d->ks[q] > 32) { vg_set_error("%s: k-steps per channel must be 1..32 (class %d: %d)", who, q, d->ks[q]); return VG_ERR_ARG; }
+        p->ksbase[q] = row; p->a_off[q] = af;
+        row += d->ks[q]; af += d->CI * d->ks[q] * 64;
+    }
+    p->kstot = row; p->aimg_floats = af;
+    if (d->nq > 1 && d->cc < d->CI) { vg_set_error("%s: multi-class plans need all input channels in one chunk", who); return VG_ERR_ARG; }
+    const int IHW = d->IH * d->IW;
+    p->CHP = MM_ZPAD + ((d->LD * IHW + 63) / 64) * 64;                   // [zero pad][LD planes]
+    p->buf_floats = d->cc * p->CHP;
+    p->a_res = 1;
+    p->tau_off = ((p->aimg_floats + 63) / 64) * 64;
+    p->in_off = p->tau_off + p->kstot * 64;
+    const size_t total = (size_t)p->in_off + 2 * (size_t)p->buf_floats + 64;
+    *shmem = total * sizeof(float);
+    if (*shmem > 160 * 1024) { vg_set_error("%s: plan needs %zu bytes of LDS", who, *shmem); return VG_ERR_UNSUPPORTED; }
+    if (d->PD * d->PH * d->PW > d->tpc * MM_W * 16) { vg_set_error("%s: %d positions per block exceed tpc=%d", who, d->PD * d->PH * d->PW, d->tpc); return VG_ERR_ARG; }
+    return VG_OK;
+}
+
+extern "C" int64_t vg_conv_mm_stats_chunks(const vg_mm_desc* d, int32_t stats_per_group) {
+    if (!d || stats_per_group <= 0 || d->PD <= 0 || d->PDT <= 0) return -1;
+    return (int64_t)stats_per_group * vg_cdiv(d->PDT, d->PD) * MM_W;
+}
+
+extern "C" int vg_conv_mm(const vg_mm_desc* d, const float* x, const float* a_img, const int32_t* tau, const int32_t* dlt,
+                          const float* bias, const float* in_scale, const float* in_shift, const float* mask_src, float* y,
+                          int32_t stats_per_group, int32_t stats_relu, double* stats_part, void* stream) {
+    MmParams p; size_t shmem;
+    int rc = mm_plan_params(d, &p, &shmem, "vg_conv_mm");
+    if (rc) return rc;
+    if (!x || !a_img || !tau || !dlt || !y) { vg_set_error("vg_conv_mm: null argument"); return VG_ERR_ARG; }
+    if ((in_scale == nullptr) != (in_shift == nullptr) || (in_scale && d->per_group <= 0)) { vg_set_error("vg_conv_mm: in_scale/in_shift/per_group inconsistent"); return VG_ERR_ARG; }
+    if (stats_part && (stats_per_group <= 0 || d->N % stats_per_group)) { vg_set_error("vg_conv_mm: bad statistics arguments"); return VG_ERR_ARG; }
+    p.has_pro = (d->relu_in || in_scale) ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(p.bps * p.nsplit), block(MM_T);
+#define MM_LAUNCH(NQ, TPC, K0, K1, K2, K3) \
+    vg_launch(conv_mm_k<NQ, TPC, K0, K1, K2, K3>, grid, block, shmem, s, x, a_img, (const int*)tau, (const int*)dlt, bias, in_scale, in_shift, \
+              mask_src, y, stats_part, (int)(stats_part ? stats_per_group : 1), (int)stats_relu, p)
+#define MM_TPC(NQ, K0, K1, K2, K3) \
+    { if (d->tpc <= 3) MM_LAUNCH(NQ, 3, K0, K1, K2, K3); else if (d->tpc <= 6) MM_LAUNCH(NQ, 6, K0, K1, K2, K3); else MM_LAUNCH(NQ, 8, K0, K1, K2, K3); }
+    const int* k = d->ks;
+    if (d->nq == 1 && d->tpc <= 8) {
+        if (k[0] == 7) MM_TPC(1, 7, 0, 0, 0)
+        else if (k[0] == 9) MM_TPC(1, 9, 0, 0, 0)
+        else if (k[0] == 12) MM_TPC(1, 12, 0, 0, 0)
+        else if (k[0] == 19 && d->tpc <= 3) MM_LAUNCH(1, 3, 19, 0, 0, 0);
+        else MM_TPC(1, 0, 0, 0, 0)
+    } else if (d->nq == 4 && d->tpc <= 4) {
+        if (k[0] == 3 && k[1] == 2 && k[2] == 2 && k[3] == 1) MM_LAUNCH(4, 4, 3, 2, 2, 1);
+        else if (k[0] == 2 && k[1] == 1 && k[2] == 1 && k[3] == 1) MM_LAUNCH(4, 4, 2, 1, 1, 1);
+        else MM_LAUNCH(4, 4, 0, 0, 0, 0);
+    } else { vg_set_error("vg_conv_mm: no kernel instance for %d classes x %d tiles per wave", d->nq, d->tpc); return VG_ERR_UNSUPPORTED; }
+#undef MM_TPC
+#undef MM_LAUNCH
+    return vg_check_launch("conv_mm");
+}
+
+namespace {
+__global__ void __launch_bounds__(256)
+gather_f32_k(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, long long n) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const int i = idx[e];
+        dst[e] = i >= 0 ? src[i] : 0.f;
+    }
+}
+}  // namespace
+
+extern "C" int vg_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, void* stream) {
+    if (!src || !idx || !dst || n <= 0) { vg_set_error("vg_gather_f32: bad arguments"); return VG_ERR_ARG; }
+    long long blocks = (n + 255) / 256; if (blocks > 1024) blocks = 1024;
+    vg_launch(gather_f32_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (const int*)idx, dst, (long long)n);
+    return vg_check_launch("gather_f32");
+}

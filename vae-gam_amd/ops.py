@@ -183,8 +183,29 @@ def pack_mode(spec: ConvSpec, direction: str) -> int:
 class PackedWeights:
     """All packed conv-weight images of a model in one buffer, refreshed by ONE launch per step."""
 
-    def __init__(self, layers, flat, offsets):
-        """layers: [(name, spec, weight Parameter)], flat: the flat fp32 parameter buffer, offsets: {name: element offset}"""
+    def __init__(self, layers, flat, offsets, sizes=None):
+        """layers: [(name, spec, weight Parameter)], flat: the flat fp32 parameter buffer, offsets: {name: element offset},
+        sizes: {name: (input spatial size, output spatial size)} -- with it the matrix-core plans (mm_plan) of every layer are
+        built too and their A images are gathered from the flat buffer by one more launch per step."""
+        self.mm = {}                                  # (name, direction) -> (MmPlan, A-image view)
+        self._mm_idx = None
+        if sizes is not None and USE_MM:
+            import numpy as np
+            idx_all, spans, pos = [], {}, 0
+            for name, spec, w in layers:
+                isz, osz = sizes[name]
+                for direction in ('fwd', 'bwd'):
+                    if direction == 'bwd' and name == 'conv1':
+                        continue
+                    plan = mm_plan(spec, 'fwd', isz) if direction == 'fwd' else mm_plan(spec, 'bwd', osz, isz)
+                    if plan is None:
+                        continue
+                    gi = np.where(plan.aidx >= 0, plan.aidx + offsets[name], -1).astype(np.int32)
+                    idx_all.append(gi); spans[(name, direction)] = (plan, pos, gi.size); pos += gi.size
+            if idx_all:
+                self._mm_idx = torch.from_numpy(np.concatenate(idx_all)).to(flat.device)
+                self._mm_buf = torch.zeros(pos, dtype=torch.float32, device=flat.device)
+                self.mm = {k: (plan, self._mm_buf[o:o + n]) for k, (plan, o, n) in spans.items()}
         segs, views, dst = [], {}, 0
         for name, spec, w in layers:
             for direction in ('fwd', 'bwd'):
@@ -205,6 +226,11 @@ class PackedWeights:
 
     def refresh(self):
         _call(self.flat, 'vg_pack_weights', _p(self.flat), _p(self.buf), _p(self.segs), self.nseg, self.elems)
+        if self._mm_idx is not None:
+            _call(self.flat, 'vg_gather_f32', _p(self.flat), _p(self._mm_idx), _p(self._mm_buf), self._mm_idx.numel())
+
+    def get_mm(self, name, direction):
+        return self.mm.get((name, direction))
 
     def get(self, name, direction):
         return self._views[(name, direction)]
@@ -465,8 +491,12 @@ class BnConvAct(torch.autograd.Function):
         with label(spec.name + '/fwd'):
             if has_bn:
                 scale, shift, mean, rstd = bn_stats(p_in, gamma, beta, relu_in, per_group, sync, pre_stats)
-            wf = packed.get(spec.name, 'fwd') if packed is not None else pack_weight(weight, spec, 'fwd')
-            y = conv_forward(p_in, wf, bias, spec, relu_in, scale, shift, per_group, next_bn)
+            mmf = _mm_for(packed, weight, spec, 'fwd', tuple(p_in.shape[2:]), None)
+            if mmf is not None:
+                y = conv_mm(p_in, mmf[0], mmf[1], bias, relu_in, scale, shift, per_group, None, next_bn)
+            else:
+                wf = packed.get(spec.name, 'fwd') if packed is not None else pack_weight(weight, spec, 'fwd')
+                y = conv_forward(p_in, wf, bias, spec, relu_in, scale, shift, per_group, next_bn)
             if next_bn:
                 y, part = y
         ctx.spec, ctx.relu_in, ctx.per_group, ctx.input_is_data, ctx.sync, ctx.has_bn = \
@@ -527,8 +557,11 @@ class BnConvAct(torch.autograd.Function):
             return None, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
         if not overlap:
             dw = conv_weight_grad(p_in, dy, spec, relu_in, scale, shift, per_group, out=wg)
-        wb = ctx.packed.get(spec.name, 'bwd') if ctx.packed is not None else pack_weight(weight, spec, 'bwd')
         in_size = tuple(p_in.shape[2:])
+        mmb = _mm_for(ctx.packed, weight, spec, 'bwd', tuple(dy.shape[2:]), in_size)
+        wb = None
+        if mmb is None:
+            wb = ctx.packed.get(spec.name, 'bwd') if ctx.packed is not None else pack_weight(weight, spec, 'bwd')
         if ctx.has_bn:
             pbg = None
             if ctx.producer_bias is not None:
@@ -541,11 +574,36 @@ class BnConvAct(torch.autograd.Function):
                 # last decoder stage: the data gradient is recomputed inside the batch-norm backward passes, never stored
                 dp, dgamma, dbeta = bn_backward_tconv1(dy, weight, p_in, gamma, mean, rstd, relu_in, per_group, ctx.sync, beta, pbg)
             else:
-                dp = conv_backward_data(dy, wb, spec, in_size, None)
+                dp = conv_mm(dy, mmb[0], mmb[1], None, False, None, None, 1, None) if mmb is not None else \
+                    conv_backward_data(dy, wb, spec, in_size, None)
                 dgamma, dbeta = bn_backward_(dp, p_in, gamma, mean, rstd, relu_in, per_group, ctx.sync, beta, pbg)
         else:
-            dp = conv_backward_data(dy, wb, spec, in_size, p_in if relu_in else None)
+            msk = p_in if relu_in else None
+            dp = conv_mm(dy, mmb[0], mmb[1], None, False, None, None, 1, msk) if mmb is not None else \
+                conv_backward_data(dy, wb, spec, in_size, msk)
         return dp, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def mm_wins(plan):
+    """Where vg_conv_mm is the faster engine (MI355X, tools/layer_bench.py at batch 64 / 8 covariates): the launches whose blocks
+    hold a whole sample (convt1 fwd 234 -> 87 us, bwd 87 -> 52; convt2 bwd 238 -> 124; conv5 fwd 30 -> 20).  On the large decoder
+    layers the first version of the kernel still loses to the register-tiled ones (one 8-wave block per CU: staging, matrix work
+    and the store phase of a unit do not overlap), so those keep the old path until it does not."""
+    return plan is not None and (USE_MM >= 2 or (plan.PDT + plan.PD - 1) // plan.PD == 1)
+
+
+def _mm_for(packed, weight, spec, direction, read_size, write_size):
+    """(plan, A image) of the matrix-core kernel for this launch, or None (-> register-tiled kernels)."""
+    if not USE_MM or (direction == 'bwd' and spec.co == 1):
+        return None
+    if packed is not None:
+        got = packed.get_mm(spec.name, direction)
+        if got is not None and (got[0].ID, got[0].IH, got[0].IW) == tuple(read_size):
+            return got if mm_wins(got[0]) else None
+    plan = mm_plan(spec, direction, read_size, write_size)
+    if not mm_wins(plan):
+        return None
+    return plan, plan.gather(weight)
 
 
 def bn_conv_act(p_in, weight, bias, gamma, beta, spec, relu_in, per_group=None, input_is_data=False, sync=None, packed=None,
@@ -889,3 +947,227 @@ def adam_step_(p, g, m, v, b1, b2, eps, step_scalars):
     assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
     _call(p, 'vg_adam_step', _p(p), _p(g), _p(m), _p(v), p.numel(), int(p.dtype == torch.float64), float(b1), float(b2),
              float(eps), _p(_chk(step_scalars, torch.float64)))
+
+
+# --------------------------------------------------------------------------- matrix-core convolution plans (vg_conv_mm)
+USE_MM = int(_os.environ.get('VG_CONV_MM', '1'))            # 0: off; 1: where it measured faster (mm_wins); 2: wherever a plan exists
+_MM_LDS_BUDGET = 150 * 1024
+_MM_WAVES = 8
+
+
+class MmPlan:
+    """Host-side description of one conv / transposed-conv launch for vg_conv_mm (include/vaegam.h): position grid, staging
+    geometry and the window-offset tables, plus `aidx` -- for every A-image slot the index of the weight it holds inside the
+    layer's own weight tensor (-1 = zero)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+        self._dev = {}
+
+    def tables(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = (torch.from_numpy(self.tau).to(device), torch.from_numpy(self.dlt).to(device), torch.from_numpy(self.aidx).to(device))
+        return self._dev[key]
+
+    def desc(self, N, relu_in, per_group):
+        d = _lib.MmDesc()
+        for k in ('CI', 'CO', 'ID', 'IH', 'IW', 'OD', 'OH', 'OW', 'nq', 'PDT', 'PH', 'PW', 'PD', 'sdi', 'shi', 'swi', 'd0', 'LD', 'cc', 'sdo', 'sho',
+                  'swo', 'tpc', 'slack'):
+            setattr(d, k, int(getattr(self, k)))
+        d.N, d.relu_in, d.per_group = int(N), int(bool(relu_in)), int(per_group)
+        for q in range(4):
+            d.ks[q] = int(self.ks[q]) if q < self.nq else 0
+            d.od0[q] = int(self.od0[q]) if q < self.nq else 0
+            d.oh0[q] = int(self.oh0[q]) if q < self.nq else 0
+            d.ow0[q] = int(self.ow0[q]) if q < self.nq else 0
+        return d
+
+    def gather(self, weight):
+        """A image from a weight tensor (layer tests / un-packed path; the model gathers all layers in one launch)."""
+        _, _, aidx = self.tables(weight.device)
+        flat = weight.detach().reshape(-1)
+        a = flat[aidx.clamp_min(0).long()]
+        return torch.where(aidx >= 0, a, torch.zeros_like(a)).contiguous()
+
+
+def _mm_problem(spec: ConvSpec, direction: str, in_size):
+    """-> (mode, S, lead_pad, CI_l, CO_l, K, out_size, widx) of the launch: mode 'corr' (strided correlation with leading zero
+    padding) or 'tconv' (stride-2 transposed convolution, gather form); widx(cin, kd, kh, kw, cout) = flat index of that weight in
+    the layer's own weight tensor (conv: [co][ci][k], convt: [ci][co][k])."""
+    import numpy as np
+    KD, KH, KW = spec.k
+    kvol = KD * KH * KW
+    conv = spec.kind == 'conv'
+
+    def w_at(ci_layer, co_layer, kd, kh, kw):
+        t = (kd * KH + kh) * KW + kw
+        return ((co_layer * spec.ci + ci_layer) if conv else (ci_layer * spec.co + co_layer)) * kvol + t
+    fl = lambda kd, kh, kw: (KD - 1 - kd, KH - 1 - kh, KW - 1 - kw)
+    if direction == 'fwd':
+        osz = spec.out_size(in_size)
+        if conv:
+            return 'corr', spec.stride, (0, 0, 0), spec.ci, spec.co, spec.k, osz, (lambda cin, kd, kh, kw, cout: w_at(cin, cout, kd, kh, kw))
+        if spec.stride == 1:
+            pad = tuple(spec.k[a] - 1 - spec.pad[a] for a in range(3))
+            return 'corr', 1, pad, spec.ci, spec.co, spec.k, osz, (lambda cin, kd, kh, kw, cout: w_at(cin, cout, *fl(kd, kh, kw)))
+        return 'tconv', 2, tuple(spec.pad), spec.ci, spec.co, spec.k, osz, (lambda cin, kd, kh, kw, cout: w_at(cin, cout, kd, kh, kw))
+    # data gradient: in_size is the size of dy (the layer's OUTPUT); the launch writes the layer's input size
+    if conv:
+        isz = None                                                       # caller passes the target size
+        if spec.stride == 1:
+            pad = tuple(spec.k[a] - 1 for a in range(3))
+            return 'corr', 1, pad, spec.co, spec.ci, spec.k, isz, (lambda cin, kd, kh, kw, cout: w_at(cout, cin, *fl(kd, kh, kw)))
+        return 'tconv', 2, (0, 0, 0), spec.co, spec.ci, spec.k, isz, (lambda cin, kd, kh, kw, cout: w_at(cout, cin, kd, kh, kw))
+    return 'corr', spec.stride, tuple(spec.pad), spec.co, spec.ci, spec.k, None, (lambda cin, kd, kh, kw, cout: w_at(cout, cin, kd, kh, kw))
+
+
+_MM_PLANS = {}
+
+
+def mm_plan(spec: ConvSpec, direction: str, in_size, out_size=None) -> Optional[MmPlan]:
+    """Plan for vg_conv_mm, or None when the launch is not covered (1-channel ends, 16-channel stride-2 transposed convs, shapes
+    that do not fit LDS): the caller then uses the register-tiled kernels.  `in_size`: spatial size of the tensor the launch READS
+    (the layer input for 'fwd', dy for 'bwd'); `out_size`: spatial size it writes (needed for 'bwd')."""
+    import numpy as np
+    key = (spec, direction, tuple(in_size), None if out_size is None else tuple(out_size))
+    if key in _MM_PLANS:
+        return _MM_PLANS[key]
+    mode, S, pad, CI, CO, K, osz, widx = _mm_problem(spec, direction, tuple(in_size))
+    if osz is None:
+        osz = tuple(out_size)
+    plan = None
+    if CO in (8, 16) and CI >= 8 and not (mode == 'tconv' and CO != 8):
+        plan = _mm_build(mode, S, pad, CI, CO, K, tuple(in_size), tuple(osz), widx)
+    _MM_PLANS[key] = plan
+    return plan
+
+
+def _mm_build(mode, S, pad, CI, CO, K, isz, osz, widx):
+    import numpy as np
+    KD, KH, KW = K
+    ID, IH, IW = isz
+    OD, OH, OW = osz
+    IHW = IH * IW
+    NR = 16 // CO
+    classes = []                                   # per class: list of (dd, dh, dw, tap(rho) -> (kd, kh, kw) or None)
+    if mode == 'corr':
+        KWp = KW + (NR - 1) * S
+        ent = []
+        for kd in range(KD):
+            for kh in range(KH):
+                for kwp in range(KWp):
+                    def tap(rho, kd=kd, kh=kh, kwp=kwp):
+                        kw = kwp - rho * S
+                        return (kd, kh, kw) if 0 <= kw < KW else None
+                    ent.append((kd - pad[0], kh - pad[1], kwp - pad[2], tap))
+        classes.append(ent)
+        PDT, PH, PW = OD, OH, (OW + NR - 1) // NR
+        sdi, shi, swi = S, S, NR * S
+        sdo, sho, swo = 1, 1, NR
+        od0, oh0, ow0 = [0], [0], [0]
+        d0 = -pad[0]
+        ld_of = lambda PD: (PD - 1) * S + KD
+    else:
+        assert NR == 2 and S == 2
+        MDm = (KD + 1) // 2
+        od0, oh0, ow0 = [], [], []
+        for rd in range(2):
+            for rh in range(2):
+                ent = []
+                for md in range((KD - rd + 1) // 2):
+                    for mh in range((KH - rh + 1) // 2):
+                        for mw in range(2):
+                            def tap(rho, rd=rd, rh=rh, md=md, mh=mh, mw=mw):
+                                kw = rho + 2 * mw
+                                return (rd + 2 * md, rh + 2 * mh, kw) if kw < KW else None
+                            ent.append((-md, -mh, -mw, tap))
+                classes.append(ent)
+                od0.append(rd - pad[0]); oh0.append(rh - pad[1]); ow0.append(-pad[2])
+        PDT, PH, PW = (OD + pad[0] + 1) // 2, (OH + pad[1] + 1) // 2, (OW + pad[2] + 1) // 2
+        sdi = shi = swi = 1
+        sdo = sho = swo = 2
+        d0 = -(MDm - 1)
+        ld_of = lambda PD: PD + MDm - 1
+    nq = len(classes)
+    if nq not in (1, 4) or any(len(e) == 0 for e in classes):
+        return None
+    ks = [(len(e) + 3) // 4 for e in classes]
+    if max(ks) > 32:
+        return None
+    rows = sum(ks)
+    tau = np.zeros((rows, 4), np.int32); dlt = np.zeros((rows, 4, 3), np.int32)
+    aidx = []
+    slack = 0
+    r0 = 0
+    for q, ent in enumerate(classes):
+        a = -np.ones((CI, ks[q], 64), np.int32)
+        for s in range(ks[q]):
+            for kk in range(4):
+                kap = 4 * s + kk
+                e = ent[kap] if kap < len(ent) else ent[0]               # padding entries: any readable offset, zero weights
+                dd, dh, dw = e[0], e[1], e[2]
+                tau[r0 + s, kk] = dd * IHW + dh * IW + dw
+                dlt[r0 + s, kk] = (dd, dh, dw)
+                slack = max(slack, abs(dh) * IW + abs(dw) + 1)
+                if kap >= len(ent):
+                    continue
+                for row in range(16):
+                    rho, co = row // CO, row % CO
+                    t = e[3](rho)
+                    if t is None:
+                        continue
+                    lane = kk * 16 + row
+                    for ci in range(CI):
+                        a[ci, s, lane] = widx(ci, t[0], t[1], t[2], co)
+        aidx.append(a.reshape(-1))
+        r0 += ks[q]
+    aidx = np.concatenate(aidx)
+    tpc_max = (8 if max(ks) <= 12 else 3) if nq == 1 else 4        # registers: one operand offset per (tile, k-step)
+    best = None
+    for PD in range(min(PDT, 16), 0, -1):
+        npos = PD * PH * PW
+        tpc = (npos + _MM_WAVES * 16 - 1) // (_MM_WAVES * 16)
+        if tpc > tpc_max:
+            continue
+        LD = ld_of(PD)
+        CHP = 64 + ((LD * IHW + 63) // 64) * 64
+        for cc in ([CI] if nq > 1 else [c for c in range(CI, 0, -1) if CI % c == 0]):
+            lds = aidx.size * 4 + rows * 64 * 4 + 2 * cc * CHP * 4 + 512
+            if lds > _MM_LDS_BUDGET:
+                continue
+            bps = (PDT + PD - 1) // PD
+            util = npos / float(tpc * _MM_WAVES * 16) * (PDT / float(bps * PD))          # filled accumulator columns
+            halo = (PD * sdi) / float(LD)                                                  # useful share of the staged planes
+            fill = min(1.0, (bps * max(1, 256 // bps)) / 256.0)
+            score = util * (0.5 + 0.5 * halo) * fill * (1.0 if cc == CI else 0.95)
+            if best is None or score > best[0] + 1e-9:
+                best = (score, PD, LD, cc, tpc)
+            break                                                                          # smaller chunks of the same PD only score lower
+    if best is None:
+        return None
+    _, PD, LD, cc, tpc = best
+    tpc = {1: (3 if tpc <= 3 else 6 if tpc <= 6 else 8), 4: 4}[nq]
+    return MmPlan(CI=CI, CO=CO, ID=ID, IH=IH, IW=IW, OD=OD, OH=OH, OW=OW, nq=nq, ks=ks, PDT=PDT, PH=PH, PW=PW, PD=PD, sdi=sdi, shi=shi,
+                  swi=swi, d0=d0, LD=LD, cc=cc, sdo=sdo, sho=sho, swo=swo, od0=od0, oh0=oh0, ow0=ow0, tpc=tpc, slack=slack,
+                  tau=tau.reshape(-1), dlt=dlt.reshape(-1), aidx=aidx, mode=mode)
+
+
+def conv_mm(x, plan: MmPlan, aimg, bias, relu_in, scale, shift, per_group, mask_src=None, next_bn=None):
+    """One vg_conv_mm launch: x [N][CI][...] -> y [N][CO][OD][OH][OW] (pre-activation); with next_bn also the statistics partials."""
+    lib = _lib.get_lib()
+    N = x.shape[0]
+    assert tuple(x.shape[1:]) == (plan.CI, plan.ID, plan.IH, plan.IW), (tuple(x.shape), plan.CI, plan.ID, plan.IH, plan.IW)
+    tau, dlt, _ = plan.tables(x.device)
+    d = plan.desc(N, relu_in, per_group if scale is not None else 1)
+    y = torch.empty((N, plan.CO, plan.OD, plan.OH, plan.OW), dtype=torch.float32, device=x.device)
+    _chk(x); _chk(aimg)
+    if next_bn:
+        chunks = lib.size('vg_conv_mm_stats_chunks', ctypes.byref(d), int(next_bn))
+        G = N // int(next_bn)
+        part = torch.zeros(G * plan.CO * chunks * 2, dtype=torch.float64, device=x.device)
+        _call(x, 'vg_conv_mm', ctypes.byref(d), _p(x), _p(aimg), _p(tau), _p(dlt), _p(bias), _p(scale), _p(shift), _p(mask_src), _p(y),
+              int(next_bn), 1, _p(part))
+        return y, part
+    _call(x, 'vg_conv_mm', ctypes.byref(d), _p(x), _p(aimg), _p(tau), _p(dlt), _p(bias), _p(scale), _p(shift), _p(mask_src), _p(y), 1, 0, None)
+    return y

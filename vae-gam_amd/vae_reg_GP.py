@@ -170,7 +170,10 @@ class VAE(nn.Module):
         g32 = self.optimizer.groups[torch.float32]
         off32 = {self.optimizer.names[i]: g32['offs'][k] for k, i in enumerate(g32['idx'])}
         convs = [(sp.name, sp, getattr(self, sp.name).weight) for sp in self.geom.enc + self.geom.dec]
-        self._packed = ops.PackedWeights(convs, g32['p'], {n: off32[n + '.weight'] for n, _, _ in convs})
+        esz, dsz = self.geom.enc_sizes(), self.geom.dec_sizes()
+        sizes = {sp.name: (esz[i], esz[i + 1]) for i, sp in enumerate(self.geom.enc)}
+        sizes.update({sp.name: (dsz[i], dsz[i + 1]) for i, sp in enumerate(self.geom.dec)})
+        self._packed = ops.PackedWeights(convs, g32['p'], {n: off32[n + '.weight'] for n, _, _ in convs}, sizes)
         self.epoch = 0
         self.loss = {'train': {}, 'test': {}}
         ts = datetime.datetime.now().date()
