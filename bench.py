@@ -99,7 +99,7 @@ def alg_bytes_per_launch(key, model, B):
     else:
         return None
     n_in = N * sp.ci * int(np.prod(sizes[i])); n_out = N * sp.co * int(np.prod(sizes[i + 1]))
-    if fn in ('vg_corr3d', 'vg_tconv3d_s2', 'vg_tconv3d_s2_stats'):
+    if fn in ('vg_corr3d', 'vg_tconv3d_s2', 'vg_tconv3d_s2_stats', 'vg_conv_mm'):
         has_mask = direction == 'bwd' and lname not in ('convt1', 'convt3', 'convt5', 'conv3', 'conv5')
         extra = n_in if has_mask else 0                       # data gradient of a layer fed by a plain ReLU: + the saved activation (mask)
         return 4 * (n_in + n_out + extra)

@@ -19,6 +19,7 @@
 // Blocks are persistent over samples: masks, position offsets, the A image and the offset table are set up once.
 #include "vg_common.h"
 #include <stdlib.h>
+#include <stdint.h>
 #include "../../include/vaegam.h"
 
 namespace {
@@ -237,15 +238,41 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
                     constexpr int KSQ = q == 0 ? K0 : q == 1 ? K1 : q == 2 ? K2 : K3;
                     constexpr int SG0 = q == 0 ? 0 : q == 1 ? K0 : q == 2 ? K0 + K1 : K0 + K1 + K2;
                     const float* Aq = Al + p.a_off[q] + (c0 + c) * KSQ * 64 + lane;
+                    // Hand-scheduled software pipeline over the k-steps: the operands of step s+1 are requested before the matrix
+                    // instructions of step s issue, and the wait in front of them is COUNTED (lgkmcnt(NT+1): everything but the NT+1 reads
+                    // just issued has landed -- LDS reads return in order).  The compiler only ever emits lgkmcnt(0) in this loop, i.e.
+                    // it waits for the reads it has just issued: every step then exposes a full LDS latency (matrix pipe busy 35 %; with
+                    // its own two-step batching 24 %).  So the reads are inline asm, which its wait-count pass does not track.
+#ifdef VG_EMU
 #pragma unroll
                     for (int s = 0; s < KSQ; ++s) {
                         const float aw = Aq[s * 64];
-                        float bv[NT];
 #pragma unroll
-                        for (int i = 0; i < NT; ++i) bv[i] = curc[pt[i][SG0 + s]];
-#pragma unroll
-                        for (int i = 0; i < NT; ++i) vg_mfma16(aw, bv[i], acc[i]);
+                        for (int i = 0; i < NT; ++i) vg_mfma16(aw, curc[pt[i][SG0 + s]], acc[i]);
                     }
+#else
+                    const unsigned cb = (unsigned)(uintptr_t)curc, ab = (unsigned)(uintptr_t)Aq;
+                    float a2[2], b2[2][NT];
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(a2[0]) : "v"(ab));
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) asm volatile("ds_read_b32 %0, %1" : "=v"(b2[0][i]) : "v"(cb + 4u * (unsigned)pt[i][SG0]));
+#pragma unroll
+                    for (int s = 0; s < KSQ; ++s) {
+                        if (s + 1 < KSQ) {
+                            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(a2[(s + 1) & 1]) : "v"(ab), "n"((s + 1) * 256));
+#pragma unroll
+                            for (int i = 0; i < NT; ++i)
+                                asm volatile("ds_read_b32 %0, %1" : "=v"(b2[(s + 1) & 1][i]) : "v"(cb + 4u * (unsigned)pt[i][SG0 + s + 1]));
+                            asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(NT + 1) : "memory");
+                        } else {
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < NT; ++i) vg_mfma16(a2[s & 1], b2[s & 1][i], acc[i]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#endif
                 } else {
                     const int ksq = d.ks[q];
                     const float* Aq = Al + p.a_off[q] + (c0 + c) * ksq * 64 + lane;
@@ -343,6 +370,8 @@ extern "C" int vg_conv_mm(const vg_mm_desc* d, const float* x, const float* a_im
         else if (k[0] == 12) MM_TPC(1, 12, 0, 0, 0)
         else if (k[0] == 19 && d->tpc <= 3) MM_LAUNCH(1, 3, 19, 0, 0, 0);
         else MM_TPC(1, 0, 0, 0, 0)
+    } else if (d->nq == 4 && d->tpc <= 7 && k[0] == 3 && k[1] == 2 && k[2] == 2 && k[3] == 1) {
+        if (d->tpc <= 4) MM_LAUNCH(4, 4, 3, 2, 2, 1); else MM_LAUNCH(4, 7, 3, 2, 2, 1);
     } else if (d->nq == 4 && d->tpc <= 4) {
         if (k[0] == 3 && k[1] == 2 && k[2] == 2 && k[3] == 1) MM_LAUNCH(4, 4, 3, 2, 2, 1);
         else if (k[0] == 2 && k[1] == 1 && k[2] == 1 && k[3] == 1) MM_LAUNCH(4, 4, 2, 1, 1, 1);

@@ -585,11 +585,22 @@ class BnConvAct(torch.autograd.Function):
 
 
 def mm_wins(plan):
-    """Where vg_conv_mm is the faster engine (MI355X, tools/layer_bench.py at batch 64 / 8 covariates): the launches whose blocks
-    hold a whole sample (convt1 fwd 234 -> 87 us, bwd 87 -> 52; convt2 bwd 238 -> 124; conv5 fwd 30 -> 20).  On the large decoder
-    layers the first version of the kernel still loses to the register-tiled ones (one 8-wave block per CU: staging, matrix work
-    and the store phase of a unit do not overlap), so those keep the old path until it does not."""
-    return plan is not None and (USE_MM >= 2 or (plan.PDT + plan.PD - 1) // plan.PD == 1)
+    """Where vg_conv_mm is the faster (or an equally fast) engine -- MI355X, tools/layer_bench.py at batch 64 / 8 covariates, us,
+    register-tiled kernel -> matrix-core kernel:
+      blocks that hold a whole sample: convt1 fwd 234 -> 84, bwd 87 -> 50; convt2 bwd 238 -> 120; conv5 fwd 30 -> 20;
+      the stride-2 transposed conv of the decoder (convt4 fwd, 4 parity classes): 890-930 -> 797, and its output is written
+      with 1.04x instead of 1.88x write traffic;
+      the 3x3x3 stride-1 layers with 8 <-> 16 channels (convt3 fwd 520-534 -> 516, bwd 442-446 -> 444; conv3): ties -- taken, so
+      that the matrix cores carry every launch that is a real contraction and the register-tiled kernels keep the 1-channel ends.
+    Kept on the register-tiled kernels: stride-2 correlations (convt4's data gradient 574 vs 714: one input channel fills the
+    LDS budget, a unit is 57 MFMAs per wave between barriers; conv2 / conv4 forward)."""
+    if plan is None:
+        return False
+    if USE_MM >= 2 or (plan.PDT + plan.PD - 1) // plan.PD == 1:
+        return True
+    if plan.mode == 'tconv':
+        return list(plan.ks) == [3, 2, 2, 1]
+    return plan.sdi == 1 and plan.ks[0] in (7, 9)
 
 
 def _mm_for(packed, weight, spec, direction, read_size, write_size):
@@ -1123,7 +1134,7 @@ def _mm_build(mode, S, pad, CI, CO, K, isz, osz, widx):
         aidx.append(a.reshape(-1))
         r0 += ks[q]
     aidx = np.concatenate(aidx)
-    tpc_max = (8 if max(ks) <= 12 else 3) if nq == 1 else 4        # registers: one operand offset per (tile, k-step)
+    tpc_max = (8 if max(ks) <= 12 else 3) if nq == 1 else (7 if ks == [3, 2, 2, 1] else 4)   # registers: one operand offset per (tile, k-step)
     best = None
     for PD in range(min(PDT, 16), 0, -1):
         npos = PD * PH * PW
@@ -1147,7 +1158,7 @@ def _mm_build(mode, S, pad, CI, CO, K, isz, osz, widx):
     if best is None:
         return None
     _, PD, LD, cc, tpc = best
-    tpc = {1: (3 if tpc <= 3 else 6 if tpc <= 6 else 8), 4: 4}[nq]
+    tpc = {1: (3 if tpc <= 3 else 6 if tpc <= 6 else 8), 4: (4 if tpc <= 4 else 7)}[nq]
     return MmPlan(CI=CI, CO=CO, ID=ID, IH=IH, IW=IW, OD=OD, OH=OH, OW=OW, nq=nq, ks=ks, PDT=PDT, PH=PH, PW=PW, PD=PD, sdi=sdi, shi=shi,
                   swi=swi, d0=d0, LD=LD, cc=cc, sdo=sdo, sho=sho, swo=swo, od0=od0, oh0=oh0, ow0=ow0, tpc=tpc, slack=slack,
                   tau=tau.reshape(-1), dlt=dlt.reshape(-1), aidx=aidx, mode=mode)
