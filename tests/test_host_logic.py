@@ -184,6 +184,25 @@ def test_nifti1_writer_round_trip_and_reference_geometry(tmp_path):
     assert struct.unpack(en + '2h', raw[70:74]) == (16, 32)
 
 
+def test_nifti1_reader_and_writer_against_spec_fixtures(tmp_path):
+    """the NIfTI-1 reader / writer against files built field by field from the format specification
+    (oracle/gen_nifti_fixture.py), not against each other: decode of both byte orders, and a byte-identical encode."""
+    from vae_gam_amd import nifti
+    GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+    want = np.fromfunction(lambda i, j, k: 100 * i + 10 * j + k, (3, 4, 5)).astype(np.float32)
+    for tag in ('le', 'be'):
+        got = DataClass_GP.read_nifti1(os.path.join(GOLDEN, 'nifti1_3x4x5_f32_%s.nii' % tag))
+        assert got.shape == (3, 4, 5)
+        np.testing.assert_array_equal(np.asarray(got, np.float32), want)
+    p = str(tmp_path / 'w.nii')
+    nifti.write_nifti1(p, want)
+    assert open(p, 'rb').read() == open(os.path.join(GOLDEN, 'nifti1_3x4x5_f32_le.nii'), 'rb').read()
+    # with a reference file the geometry comes from it, in its byte order
+    p2 = str(tmp_path / 'w_be.nii')
+    nifti.write_nifti1(p2, want, reference=os.path.join(GOLDEN, 'nifti1_3x4x5_f32_be.nii'))
+    assert open(p2, 'rb').read() == open(os.path.join(GOLDEN, 'nifti1_3x4x5_f32_be.nii'), 'rb').read()
+
+
 def test_mk_avg_maps_from_device_sums(tmp_path):
     """Subject means and the grand mean (mean of subject means, build_model_recons.py:86-99) from the sums reconstruct() leaves."""
     import pandas as pd

@@ -21,7 +21,7 @@ def _subjects(csv_file):
     return dset.iloc[:, 1].unique().tolist(), dset.iloc[:, 3].unique().tolist()          # subjid, nii_path (positional, as DataClass_GP)
 
 
-def mk_single_volumes(loader, model, csv_file, save_dir, write_volumes=True):
+def mk_single_volumes(loader, model, csv_file, save_dir, write_volumes=True, noise=None):
     subjs, ref_niis = _subjects(csv_file)
     ckpt_num = str(model.epoch).zfill(3)
     subj_dirs = []
@@ -29,7 +29,7 @@ def mk_single_volumes(loader, model, csv_file, save_dir, write_volumes=True):
         d = os.path.join(save_dir, 'reconstructions', '{}_model_recons'.format(ckpt_num), str(s))
         os.makedirs(d, exist_ok=True)
         subj_dirs.append(d)
-    model.reconstruct(loader, ref_niis, subj_dirs, write_volumes=write_volumes)
+    model.reconstruct(loader, ref_niis, subj_dirs, write_volumes=write_volumes, noise=noise)
 
 
 def mk_avg_maps(csv_file, model, save_dir, mk_motion_maps=False, loader=None):

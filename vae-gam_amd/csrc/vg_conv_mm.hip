@@ -370,8 +370,6 @@ extern "C" int vg_conv_mm(const vg_mm_desc* d, const float* x, const float* a_im
         else if (k[0] == 12) MM_TPC(1, 12, 0, 0, 0)
         else if (k[0] == 19 && d->tpc <= 3) MM_LAUNCH(1, 3, 19, 0, 0, 0);
         else MM_TPC(1, 0, 0, 0, 0)
-    } else if (d->nq == 4 && d->tpc <= 7 && k[0] == 3 && k[1] == 2 && k[2] == 2 && k[3] == 1) {
-        if (d->tpc <= 4) MM_LAUNCH(4, 4, 3, 2, 2, 1); else MM_LAUNCH(4, 7, 3, 2, 2, 1);
     } else if (d->nq == 4 && d->tpc <= 4) {
         if (k[0] == 3 && k[1] == 2 && k[2] == 2 && k[3] == 1) MM_LAUNCH(4, 4, 3, 2, 2, 1);
         else if (k[0] == 2 && k[1] == 1 && k[2] == 1 && k[3] == 1) MM_LAUNCH(4, 4, 2, 1, 1, 1);

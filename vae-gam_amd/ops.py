@@ -1134,7 +1134,7 @@ def _mm_build(mode, S, pad, CI, CO, K, isz, osz, widx):
         aidx.append(a.reshape(-1))
         r0 += ks[q]
     aidx = np.concatenate(aidx)
-    tpc_max = (8 if max(ks) <= 12 else 3) if nq == 1 else (7 if ks == [3, 2, 2, 1] else 4)   # registers: one operand offset per (tile, k-step)
+    tpc_max = (8 if max(ks) <= 12 else 3) if nq == 1 else 4        # registers: one operand offset per (tile, k-step)
     best = None
     for PD in range(min(PDT, 16), 0, -1):
         npos = PD * PH * PW
@@ -1158,7 +1158,7 @@ def _mm_build(mode, S, pad, CI, CO, K, isz, osz, widx):
     if best is None:
         return None
     _, PD, LD, cc, tpc = best
-    tpc = {1: (3 if tpc <= 3 else 6 if tpc <= 6 else 8), 4: (4 if tpc <= 4 else 7)}[nq]
+    tpc = {1: (3 if tpc <= 3 else 6 if tpc <= 6 else 8), 4: 4}[nq]
     return MmPlan(CI=CI, CO=CO, ID=ID, IH=IH, IW=IW, OD=OD, OH=OH, OW=OW, nq=nq, ks=ks, PDT=PDT, PH=PH, PW=PW, PD=PD, sdi=sdi, shi=shi,
                   swi=swi, d0=d0, LD=LD, cc=cc, sdo=sdo, sho=sho, swo=swo, od0=od0, oh0=oh0, ow0=ow0, tpc=tpc, slack=slack,
                   tau=tau.reshape(-1), dlt=dlt.reshape(-1), aidx=aidx, mode=mode)

@@ -699,12 +699,13 @@ class VAE(nn.Module):
         self.inducing_pts = checkpoint['inducing_pts']
 
     # ------------------------------------------------------------------ post-hoc (reconstruction export lives in build_model_recons)
-    def reconstruct(self, loader, ref_niis, save_dirs, write_volumes=True):
+    def reconstruct(self, loader, ref_niis, save_dirs, write_volumes=True, noise=None):
         """Reference signature (vae_reg_GP.py:585-620): one `recon_<map>.nii` per volume and map under
         save_dirs[subject]/vol_<n>/, written with the geometry of that subject's reference NIfTI.
         The maps stay on the device until they are written; per-subject sums of every map are accumulated there as
         well (`self.recon_sums`), so that build_model_recons.mk_avg_maps does not have to re-read the files.
-        write_volumes=False only accumulates."""
+        write_volumes=False only accumulates.  `noise`: optional callable (batch index, batch size) -> the dict forward_core takes,
+        to replay recorded draws (parity tests); by default every batch draws its own, as the reference does."""
         import os
         from . import nifti
         C = self.num_covariates
@@ -714,9 +715,9 @@ class VAE(nn.Module):
         counts = torch.zeros(S, device=self.device, dtype=torch.float64)
         refs = {}
         with torch.no_grad():
-            for sample in loader:
+            for bi, sample in enumerate(loader):
                 ids, covariates, x = self._batch_to_device(sample)
-                out = self.forward_core(covariates, x, want_maps=True)
+                out = self.forward_core(covariates, x, noise=None if noise is None else noise(bi, int(x.shape[0])), want_maps=True)
                 maps = out['maps']                                         # (C+2, B, V) on the device
                 idl = ids.long()
                 counts.index_add_(0, idl, torch.ones_like(idl, dtype=torch.float64))
