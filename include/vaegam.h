@@ -111,6 +111,16 @@ int64_t vg_wgrad3d_ws_bytes(const vg_wgrad_desc* d);
 int vg_wgrad3d(const vg_wgrad_desc* d, const float* a, const float* b, const float* in_scale,
                const float* in_shift, float* ws, float* dw, int32_t accumulate, void* stream);
 
+/* The same contraction kept PER BATCH-NORM GROUP (g = n / per_group), plus one extra row: out[g][cb][ca*KVOL + tap] for cb < CB is
+ * group g's share of dw; row cb == CB is the contraction of `a` with a constant-one position channel, i.e. the per-tap sums of the
+ * window tensor over the positions each tap meets.  Called with in_scale = rstd, in_shift = -mean*rstd (the prologue then produces the
+ * NORMALISED activation) it yields everything the batch-norm backward of the layer in front needs (vg_bn_tconv1_sums) without a pass
+ * over the data.  Supported: CA == 1, 3x3x3, stride 1, no padding, CB < 16, prologue on b (the decoder's last stage); otherwise
+ * VG_ERR_UNSUPPORTED.  out: float[N/per_group][CB+1][CA*KVOL], overwritten.  ws: vg_wgrad3d_grouped_ws_bytes(d) bytes. */
+int64_t vg_wgrad3d_grouped_ws_bytes(const vg_wgrad_desc* d);
+int vg_wgrad3d_grouped(const vg_wgrad_desc* d, const float* a, const float* b, const float* in_scale,
+                       const float* in_shift, float* ws, float* out, void* stream);
+
 /* batch-norm batch statistics (BatchNorm3d(track_running_stats=False), vae_reg_GP.py:194-196,
  * 216-218): for x [N][C][P], group g = n / per_group: mean/var over (per_group samples, P) of
  * relu?(x); writes scale = gamma*rstd, shift = beta - mean*scale, mean, rstd ([G][C] each).
@@ -160,6 +170,14 @@ int vg_bn_bwd_reduce_tconv1(const float* dy, const float* w, const float* p, int
 int vg_bn_bwd_apply_tconv1(const float* dy, const float* w, const float* p, float* dp, int32_t N, int32_t C, int32_t ID, int32_t IH,
                            int32_t IW, int32_t per_group, int32_t relu, const float* gamma, const float* mean, const float* rstd,
                            const double* sums, double count, void* ws, float* chsum, int32_t chsum_accumulate, void* stream);
+
+/* The reduce pass of the pair above WITHOUT reading p or dy again, from the grouped weight gradient of the transposed conv taken
+ * against the normalised activation (q = vg_wgrad3d_grouped(...) with in_scale = rstd, in_shift = -mean*rstd; [G][C+1][K], K = 27):
+ *   sums[g][c] = { sum_k w[c][k] q[g][C][k],  sum_k w[c][k] q[g][c][k] }         (= {sum dxe, sum dxe*hhat}, double[G][C][2])
+ *   dw[c][k] (+)= gamma[c] * sum_g q[g][c][k] + beta[c] * sum_g q[g][C][k]       (the conv's own weight gradient, its layout)
+ * (autograd of convt5(bnt5(.)), vae_reg_GP.py:218,264: conv_transpose3d's weight gradient and batch_norm's two reductions). */
+int vg_bn_tconv1_sums(const float* q, const float* w, const float* gamma, const float* beta, int32_t G, int32_t C, int32_t K,
+                      double* sums, float* dw, int32_t accumulate, void* stream);
 
 /* per-channel sum of a [N][C][P] tensor (bias gradients): out[c] = sum_{n,p} x[n][c][p] */
 int vg_channel_sum(const float* x, int32_t N, int32_t C, int64_t P, void* ws, float* out, int32_t accumulate, void* stream);

@@ -48,6 +48,9 @@ _PROTOS = {
     'vg_bn_stats_from_parts': (ctypes.c_int, [vp, i32, i32, i64, f64, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),
     'vg_wgrad3d_ws_bytes': (i64, [ctypes.POINTER(WgradDesc)]),
     'vg_wgrad3d': (ctypes.c_int, [ctypes.POINTER(WgradDesc), vp, vp, vp, vp, vp, vp, i32, vp]),
+    'vg_wgrad3d_grouped_ws_bytes': (i64, [ctypes.POINTER(WgradDesc)]),
+    'vg_wgrad3d_grouped': (ctypes.c_int, [ctypes.POINTER(WgradDesc), vp, vp, vp, vp, vp, vp, vp]),
+    'vg_bn_tconv1_sums': (ctypes.c_int, [vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp]),
     'vg_bn_ws_bytes': (i64, [i32, i32, i64, i32]),
     'vg_bn_stats': (ctypes.c_int, [vp, i32, i32, i64, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]),
     'vg_bn_finalize': (ctypes.c_int, [vp, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp]),

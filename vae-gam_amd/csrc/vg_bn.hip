@@ -504,6 +504,39 @@ extern "C" int vg_bn_bwd_reduce_tconv1(const float* dy, const float* w, const fl
     return vg_check_launch("bn_bwd_reduce_tconv1 fold");
 }
 
+// Batch-norm backward sums of the layer in front of a one-output-channel transposed conv WITHOUT a pass over the data.
+// With dxe[c][q] = sum_k w[c][k] dy[q+k] (the conv's data gradient) and Q[g][c][k] = sum_{n in g, q} hhat[n][c][q] dy[n][q+k]
+// (the conv's weight gradient taken against the NORMALISED input), S[g][k] = sum_{n in g, q} dy[n][q+k]:
+//   sum dxe      = sum_k w[c][k] S[g][k]          sum dxe*hhat = sum_k w[c][k] Q[g][c][k]
+//   dw[c][k]     = gamma[c] sum_g Q[g][c][k] + beta[c] sum_g S[g][k]      (the input of the conv is gamma*hhat + beta)
+// q = vg_wgrad3d_grouped's output [G][C+1][K] (row C holds S).  One block; G*C and C*K are a few hundred.
+__global__ void __launch_bounds__(256)
+bn_tconv1_sums_k(const float* __restrict__ q, const float* __restrict__ w, const float* __restrict__ gamma,
+                 const float* __restrict__ beta, int G, int C, int K, double* __restrict__ sums, float* __restrict__ dw, int accumulate) {
+    for (int i = threadIdx.x; i < G * C; i += blockDim.x) {
+        const int g = i / C, c = i % C;
+        const float* Q = q + ((size_t)g * (C + 1) + c) * K;
+        const float* S = q + ((size_t)g * (C + 1) + C) * K;
+        double s0 = 0, s1 = 0;
+        for (int k = 0; k < K; ++k) { const double wv = w[c * K + k]; s0 += wv * S[k]; s1 += wv * Q[k]; }
+        sums[(size_t)i * 2] = s0; sums[(size_t)i * 2 + 1] = s1;
+    }
+    for (int j = threadIdx.x; j < C * K; j += blockDim.x) {
+        const int c = j / K, k = j % K;
+        double a = 0, b = 0;
+        for (int g = 0; g < G; ++g) { a += q[((size_t)g * (C + 1) + c) * K + k]; b += q[((size_t)g * (C + 1) + C) * K + k]; }
+        const float v = (float)((double)gamma[c] * a + (double)beta[c] * b);
+        dw[j] = accumulate ? dw[j] + v : v;
+    }
+}
+
+extern "C" int vg_bn_tconv1_sums(const float* q, const float* w, const float* gamma, const float* beta, int32_t G, int32_t C, int32_t K,
+                                 double* sums, float* dw, int32_t accumulate, void* stream) {
+    if (!q || !w || !gamma || !beta || !sums || !dw || G <= 0 || C <= 0 || K <= 0) { vg_set_error("vg_bn_tconv1_sums: bad argument"); return VG_ERR_ARG; }
+    vg_launch(bn_tconv1_sums_k, dim3(1), dim3(256), 0, (hipStream_t)stream, q, w, gamma, beta, (int)G, (int)C, (int)K, sums, dw, (int)accumulate);
+    return vg_check_launch("bn_tconv1_sums");
+}
+
 extern "C" int vg_bn_bwd_apply_tconv1(const float* dy, const float* w, const float* p, float* dp, int32_t N, int32_t C, int32_t ID,
                                       int32_t IH, int32_t IW, int32_t per_group, int32_t relu, const float* gamma, const float* mean,
                                       const float* rstd, const double* sums, double count, void* ws, float* chsum,

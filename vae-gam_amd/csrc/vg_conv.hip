@@ -248,7 +248,7 @@ struct CorrPlaneParams {
 constexpr int PLANE_SLACK = 8;  // floats in front of the LDS buffer: a window may start at iw = -pad
 
 template <int COT, int KD, int KH, int KW, int S, int TDt, int THt, int TW, int COC>
-__global__ void __launch_bounds__(256, 3)
+__global__ void __launch_bounds__(256, (TDt * THt * TW > 16 ? 2 : 3))
 corr3d_plane_k(const float* __restrict__ x, const float* __restrict__ wpk, const float* __restrict__ bias,
                const float* __restrict__ in_scale, const float* __restrict__ in_shift,
                const float* __restrict__ mask_src, float* __restrict__ y, CorrPlaneParams p) {
@@ -469,7 +469,7 @@ int launch_corr_plane(const vg_conv_desc* d, const float* x, const float* wpk, c
     // Measured on MI355X: no gain where the chunk is small (convt3/convt4: 3 blocks per CU already hide the fill) and a
     // loss where it doubles a 25 KB slot (convt5 forward 244 -> 341 us: only two 52 KB blocks fit a CU). Off by default.
     static const int nbuf_env = getenv("VG_PLANE_NBUF") ? atoi(getenv("VG_PLANE_NBUF")) : 0;
-    const size_t budget2 = 52 * 1024;
+    const size_t budget2 = (TDt * THt * TW > 16 ? 78 : 52) * 1024;      // two blocks per CU there (registers), three otherwise
     p.nbuf = (nbuf_env == 2 && d->CI > 1 && 2 * (size_t)p.ch_floats * sizeof(float) + (PLANE_SLACK + 64) * sizeof(float) <= budget2) ? 2 : 1;
     const size_t bud = p.nbuf == 2 ? budget2 : budget;
     int cch = (int)((bud - (PLANE_SLACK + 64) * sizeof(float)) / ((size_t)p.ch_floats * sizeof(float) * p.nbuf));
@@ -947,6 +947,7 @@ extern "C" int vg_corr3d(const vg_conv_desc* d, const float* x, const float* wpk
     if (d->KD == 4 && d->KH == 4 && d->KW == 4 && d->stride == 2) CORR_MFMA(4, 4, 4, 2)
 #undef CORR_MFMA
     if (k333 && d->stride == 1) {
+        if (d->CO == 1 && getenv("VG_C5_TDT4")) CORR_LDS(1, 3, 3, 3, 1, 4, 2, 4);
         if (d->CO == 1) CORR_LDS(1, 3, 3, 3, 1, 2, 2, 4);
         if (d->CO % 8 == 0 && !small) CORR_LDS_RT(8, 3, 3, 3, 1, 1, 1, 4);
         if (d->CO % 4 == 0 && small) CORR(4, 3, 3, 3, 1, 1, 1, 2);

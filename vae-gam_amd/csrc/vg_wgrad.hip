@@ -720,6 +720,11 @@ int launch_plane(const vg_wgrad_desc* d, const float* a, const float* b, const f
 //    span per plane for the flat LDS-DMA), so a tile is ~20-30 KB instead of 60 KB and 3-8 blocks share a CU: one
 //    block's DMA + barriers hide behind the others' MFMAs.
 // ------------------------------------------------------------------------------------------
+#ifdef VG_EMU
+#define VG_WG_FENCE() ((void)0)
+#else
+#define VG_WG_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 template <int V> struct vg_int { static constexpr int value = V; };
 template <int N, int I = 0, typename F>
 __host__ __device__ inline void vg_static_for(F&& f) { if constexpr (I < N) { f(vg_int<I>{}); vg_static_for<N, I + 1>(f); } }
@@ -734,10 +739,15 @@ struct WgradRowsParams {
     int lds_floats;
     int items;
     int wave_slabs;             // small grids: every wave writes its own slab (no cross-wave LDS reduction: 4 serial rounds, ~13 us)
+    // grouped mode (vg_wgrad3d_grouped): a block owns a CONTIGUOUS range of ipb items and closes a slab whenever the batch-norm group
+    // (sample / per_group) changes inside it -- at most once (ipb <= grp_items) -- so every slab belongs to one group: two slabs per block
+    int grp_items;              // items per group (0: plain mode, round-robin items, one slab per block)
+    int ipb;                    // items per block
+    int ones_row;               // 1: MFMA row CB carries a constant-one position channel -> per-tap sums of the window tensor
 };
 
-template <int CA, int TC, int KD, int KH, int KW, int S, bool PAD, bool PA, int UG, bool RES>
-__global__ void __launch_bounds__(256)
+template <int CA, int TC, int KD, int KH, int KW, int S, bool PAD, bool PA, int UG, bool RES, bool GRP = false>
+__global__ void __launch_bounds__(256, (CA * TC >= 32 ? 2 : 1))         // 32 accumulator tiles: keep two waves per SIMD (<= 256 registers)
 wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ in_scale,
              const float* __restrict__ in_shift, float* __restrict__ ws, WgradRowsParams p) {
     VG_DYN_SMEM(float, lds);
@@ -772,7 +782,62 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
     const float* bchan = btile + min(cbl, CB - 1) * p.bch + kq;
     __syncthreads();
 
-    for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
+    const int CBW = CB + (GRP ? 1 : 0);                                  // rows of dw written out (grouped: + the ones row)
+    const int ncol_o = CA * KVOL;
+    // ---- close a slab: the block's (or, small grids, each wave's) partial dw -> workspace
+    auto write_out = [&](int slab) {
+        if (p.wave_slabs) {
+            float* out = ws + ((size_t)slab * nwaves + wave) * CBW * ncol_o;
+            const int cb0 = (lane >> 4) * 4, tapl = lane & 15;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int ca = t / TC, tap = (t % TC) * 16 + tapl;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (cb0 + r < CBW && tap < KVOL) out[(size_t)(cb0 + r) * ncol_o + ca * KVOL + tap] = acc[t].v[r];
+                VG_WG_FENCE();                      // one tile at a time: otherwise all NT*4 accumulators are copied to VGPRs up front
+            }
+            return;
+        }
+        // cross-wave reduction through LDS (one wave at a time), then one slab
+        float* red = lds;
+        __syncthreads();
+        for (int w = 0; w < nwaves; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int idx = (t * 4 + r) * VG_WAVE + lane;
+                        red[idx] = (w == 0 ? 0.f : red[idx]) + acc[t].v[r];
+                        if (r == 3) VG_WG_FENCE();
+                    }
+            }
+            __syncthreads();
+        }
+        float* out = ws + (size_t)slab * CBW * ncol_o;
+        for (int i = tid; i < NT * 4 * VG_WAVE; i += blockDim.x) {
+            const int l = i % VG_WAVE; const int r = (i / VG_WAVE) % 4; const int t = i / (4 * VG_WAVE);
+            const int ca = t / TC, tap = (t % TC) * 16 + (l & 15);
+            const int cb = (l >> 4) * 4 + r;
+            if (cb < CBW && tap < KVOL) out[(size_t)cb * ncol_o + ca * KVOL + tap] = red[i];
+        }
+    };
+    // plain mode: one segment, items blockIdx.x, +gridDim.x, ...; grouped mode: two segments, the block's contiguous item range split
+    // at the group boundary inside it (the second one empty if there is none) -- ONE copy of the loop body and of the slab write-out
+    // (GRP is a template parameter: the segment loop costs the plain instances ~50 VGPRs -- one wave per SIMD less -- if it is a run-time mode)
+    const int it_step = GRP ? 1 : (int)gridDim.x;
+    const int it0 = GRP ? (int)blockIdx.x * p.ipb : (int)blockIdx.x;
+    const int it1 = GRP ? min(it0 + p.ipb, p.items) : p.items;
+    const int split = GRP ? min((it0 / p.grp_items + 1) * p.grp_items, it1) : it1;
+    constexpr int nseg = GRP ? 2 : 1;
+
+    for (int seg = 0; seg < nseg; ++seg) {
+    if (GRP) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { acc[t].v[0] = 0.f; acc[t].v[1] = 0.f; acc[t].v[2] = 0.f; acc[t].v[3] = 0.f; }
+    }
+    for (int item = seg ? split : it0; item < (seg || !GRP ? it1 : split); item += it_step) {
         const int n = item / (p.pdblocks * p.nph); const int rem = item % (p.pdblocks * p.nph);
         const int pd0 = (rem / p.nph) * p.TPD, ph0 = (rem % p.nph) * p.TPH;
         const int nrow = min(p.TPH, d.PH - ph0), ndz = min(p.TPD, d.PD - pd0);
@@ -786,6 +851,7 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
         const float* abase = a + (((size_t)n * CA * d.AD + pl_lo) * d.AH + r_lo) * d.AW;
         float bsc = cb_ok ? 1.f : 0.f, bsh = 0.f;                        // lanes without a b channel contribute zeros
         if (!PA && in_scale && cb_ok) { bsc = in_scale[g * CB + cbl]; bsh = in_shift[g * CB + cbl]; }
+        if (GRP && cbl == CB) bsh = 1.f;                                 // ones row (bsc stays 0: the lane reads channel CB-1's finite data)
         __syncthreads();                                                  // previous item's tiles fully consumed
         // one (channel, plane) span per wave at a time: the span's base addresses are formed once, the 256-byte DMA
         // instructions of the span then cost a handful of scalar adds each (a flattened loop pays two scalar divisions
@@ -898,47 +964,40 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
             });
         }
     }
-    if (p.wave_slabs) {
-        float* out = ws + ((size_t)blockIdx.x * nwaves + wave) * CB * (CA * KVOL);
-        const int cb0 = (lane >> 4) * 4, tapl = lane & 15;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int ca = t / TC, tap = (t % TC) * 16 + tapl;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (cb0 + r < CB && tap < KVOL) out[(size_t)(cb0 + r) * (CA * KVOL) + ca * KVOL + tap] = acc[t].v[r];
-        }
-        return;
+    write_out((int)blockIdx.x * nseg + seg);
     }
-    // ---- cross-wave reduction through LDS (one wave at a time), then one slab per block
-    float* red = lds;
+}
+
+// Slabs of a grouped launch -> out[g][len].  Block (i-chunk, g) walks the blocks whose item range touches group g; of their two
+// slabs it takes those that belong to g (slab 0: the group of the block's first item, slab 1: of its last item).
+__global__ void __launch_bounds__(64 * SLAB_ROWS)
+slab_sum_groups_k(const float* __restrict__ ws, int nblocks, int per_slab, int len, int ipb, int grp_items, int items,
+                  float* __restrict__ out) {
+    __shared__ float red[SLAB_ROWS][64];
+    const int j = threadIdx.x % 64, r = threadIdx.x / 64;
+    const int i = blockIdx.x * 64 + j, g = blockIdx.y;
+    const int b_lo = (g * grp_items) / ipb, b_hi = min(((g + 1) * grp_items - 1) / ipb, nblocks - 1);
+    float s0 = 0.f;
+    if (i < len)
+        for (int k = b_lo * 2 * per_slab + r; k < (b_hi + 1) * 2 * per_slab; k += SLAB_ROWS) {
+            const int bs = k / per_slab, blk = bs >> 1, sg = bs & 1;
+            const int first = blk * ipb, last = min(first + ipb, items) - 1;
+            if ((sg ? last : first) / grp_items == g) s0 += ws[(size_t)k * len + i];
+        }
+    red[r][j] = s0;
     __syncthreads();
-    for (int w = 0; w < nwaves; ++w) {
-        if (wave == w) {
+    if (r == 0 && i < len) {
+        float t = 0.f;
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int idx = (t * 4 + r) * VG_WAVE + lane;
-                    red[idx] = (w == 0 ? 0.f : red[idx]) + acc[t].v[r];
-                }
-        }
-        __syncthreads();
-    }
-    const int ncol = CA * KVOL;
-    float* out = ws + (size_t)blockIdx.x * CB * ncol;
-    for (int i = tid; i < NT * 4 * VG_WAVE; i += blockDim.x) {
-        const int l = i % VG_WAVE; const int r = (i / VG_WAVE) % 4; const int t = i / (4 * VG_WAVE);
-        const int ca = t / TC, tap = (t % TC) * 16 + (l & 15);
-        const int cb = (l >> 4) * 4 + r;
-        if (cb < CB && tap < KVOL) out[(size_t)cb * ncol + ca * KVOL + tap] = red[i];
+        for (int q = 0; q < SLAB_ROWS; ++q) t += red[q][j];
+        out[(size_t)g * len + i] = t;
     }
 }
 
 // returns -1 when the geometry does not fit (caller falls back)
 template <int CA, int TC, int KD, int KH, int KW, int S, bool PAD>
 int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const float* in_scale, const float* in_shift,
-                float* ws, float* dw, hipStream_t s, int64_t* ws_bytes_only, int accumulate) {
+                float* ws, float* dw, hipStream_t s, int64_t* ws_bytes_only, int accumulate, int grouped = 0) {
     constexpr int KVOL = KD * KH * KW;
     constexpr int NT = CA * TC;
     const bool padded = d->pad_d || d->pad_h || d->pad_w;
@@ -1000,18 +1059,41 @@ int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const fl
     if (CA > 1 && res) kern = d->pro_on_a ? VG_PICK(true, true) : VG_PICK(false, true);
     else kern = d->pro_on_a ? VG_PICK(true, false) : VG_PICK(false, false);
 #undef VG_PICK
+    if (grouped) {
+        if constexpr (CA == 1 && !PAD) {
+            if (d->pro_on_a) return -1;
+            kern = ug == 4 ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 4, false, true> : ug == 3 ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 3, false, true>
+                           : wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 2, false, true>;
+        } else return -1;
+    }
     int per_cu = vg_blocks_per_cu((const void*)kern, 256, fl * sizeof(float));   // persistent grid == resident blocks
     if (per_cu > 8) per_cu = 8;
     { static const int cap_blocks = getenv("VG_WGRAD_BLOCKS_PER_CU") ? atoi(getenv("VG_WGRAD_BLOCKS_PER_CU")) : 0;
       if (cap_blocks > 0 && per_cu > cap_blocks) per_cu = cap_blocks; }
     int grid = 256 * per_cu; if (grid > p.items) grid = p.items;
-    const int len = d->CB * CA * KVOL;
+    p.grp_items = 0; p.ipb = 0; p.ones_row = 0;
+    if (grouped) {
+        // per-group partials (+ the ones row): contiguous item ranges, at most one group boundary per block
+        if (d->CB >= 16) return -1;                                    // the ones row needs a free MFMA row
+        p.grp_items = d->per_group * p.pdblocks * p.nph; p.ones_row = 1;
+        p.ipb = vg_cdiv(p.items, grid);
+        if (p.ipb > p.grp_items) p.ipb = p.grp_items;
+        grid = vg_cdiv(p.items, p.ipb);
+    }
+    const int len = (d->CB + p.ones_row) * CA * KVOL;
     p.wave_slabs = grid <= 512 ? 1 : 0;
-    const int nslabs = p.wave_slabs ? grid * 4 : grid;
+    const int per_slab = p.wave_slabs ? 4 : 1;
+    const int nslabs = grid * per_slab * (grouped ? 2 : 1);
     if (ws_bytes_only) { *ws_bytes_only = (int64_t)nslabs * len * sizeof(float); return VG_OK; }
     vg_launch(kern, dim3(grid), dim3(256), fl * sizeof(float), s, a, b, in_scale, in_shift, ws, p);
     int rc = vg_check_launch("wgrad_rows");
     if (rc) return rc;
+    if (grouped) {
+        const int G = d->N / d->per_group;
+        vg_launch(slab_sum_groups_k, dim3(vg_cdiv(len, 64), G), dim3(64 * SLAB_ROWS), 0, s, (const float*)ws, grid, per_slab, len,
+                  p.ipb, p.grp_items, p.items, dw);
+        return vg_check_launch("wgrad slab_sum_groups");
+    }
     vg_launch(slab_sum_k, dim3(vg_cdiv(len, 64)), dim3(64 * SLAB_ROWS), 0, s, (const float*)ws, nslabs, len, accumulate, dw);
     return vg_check_launch("wgrad slab_sum");
 }
@@ -1157,6 +1239,33 @@ int dispatch(const vg_wgrad_desc* d, const float* a, const float* b, const float
 }
 
 }  // namespace
+
+static int grouped_dispatch(const vg_wgrad_desc* d, const float* a, const float* b, const float* in_scale, const float* in_shift,
+                            float* ws, float* out, hipStream_t s, int64_t* ws_only) {
+    if (!d) { vg_set_error("vg_wgrad3d_grouped: null descriptor"); return VG_ERR_ARG; }
+    if (d->N <= 0 || d->per_group <= 0 || d->N % d->per_group || d->CB <= 0 || d->CB >= 16 || d->PD <= 0 || d->PH <= 0 || d->PW <= 0) {
+        vg_set_error("vg_wgrad3d_grouped: bad shape"); return VG_ERR_ARG;
+    }
+    const bool k333 = d->KD == 3 && d->KH == 3 && d->KW == 3;
+    if (k333 && d->CA == 1 && d->stride == 1 && !d->pad_d && !d->pad_h && !d->pad_w && d->PW <= 64) {
+        int r_ = launch_rows<1, 2, 3, 3, 3, 1, false>(d, a, b, in_scale, in_shift, ws, out, s, ws_only, 0, 1);
+        if (r_ >= 0) return r_;
+    }
+    vg_set_error("vg_wgrad3d_grouped: no kernel instance for CB=%d CA=%d k=%dx%dx%d stride=%d", d->CB, d->CA, d->KD, d->KH, d->KW, d->stride);
+    return VG_ERR_UNSUPPORTED;
+}
+
+extern "C" int64_t vg_wgrad3d_grouped_ws_bytes(const vg_wgrad_desc* d) {
+    int64_t bytes = 0;
+    int rc = grouped_dispatch(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &bytes);
+    return rc ? -1 : bytes;
+}
+
+extern "C" int vg_wgrad3d_grouped(const vg_wgrad_desc* d, const float* a, const float* b, const float* in_scale,
+                                  const float* in_shift, float* ws, float* out, void* stream) {
+    if (!a || !b || !ws || !out || !in_scale || !in_shift) { vg_set_error("vg_wgrad3d_grouped: null argument"); return VG_ERR_ARG; }
+    return grouped_dispatch(d, a, b, in_scale, in_shift, ws, out, (hipStream_t)stream, nullptr);
+}
 
 extern "C" int64_t vg_wgrad3d_ws_bytes(const vg_wgrad_desc* d) {
     int64_t bytes = 0;

@@ -62,6 +62,7 @@ def _call(t, fn, *args):
 import os as _os
 SIDE_STREAM = bool(int(_os.environ.get('VG_SIDE_STREAM', '0')))
 FUSE_LAST_BN_BWD = bool(int(_os.environ.get('VG_FUSE_LAST_BN_BWD', '1')))     # bnt5 backward + convt5 data gradient in two fused passes
+WGRAD_BN_SUMS = bool(int(_os.environ.get('VG_WGRAD_BN_SUMS', '1')))          # bnt5's backward reductions from convt5's grouped weight gradient (no reduce pass)
 FC_SIDE_STREAM = bool(int(_os.environ.get('VG_FC_SIDE_STREAM', '0')))     # fully connected dW/db on the second stream: measured 4.41 vs 4.28 ms/step (worse), off
 _SIDE = {}
 
@@ -410,11 +411,27 @@ def bn_backward_(dxe, p, gamma, mean, rstd, relu, per_group, sync=None, beta=Non
     return dg, db
 
 
-def bn_backward_tconv1(dy, weight, p, gamma, mean, rstd, relu, per_group, sync=None, beta=None, producer_bias_grad=None):
+_GROUPED_OK = {}
+
+
+def _grouped_wgrad_ok(p_shape, per_group):
+    """Whether vg_wgrad3d_grouped has an instance for the last decoder stage at this geometry (asked once per shape)."""
+    key = (tuple(p_shape), int(per_group))
+    if key not in _GROUPED_OK:
+        N, C, ID, IH, IW = key[0]
+        d = WgradDesc(N, C, 1, ID, IH, IW, ID + 2, IH + 2, IW + 2, 3, 3, 3, 1, 0, 0, 0, 0, 0, int(per_group))
+        _GROUPED_OK[key] = _lib.get_lib().dll.vg_wgrad3d_grouped_ws_bytes(ctypes.byref(d)) >= 0
+    return _GROUPED_OK[key]
+
+
+def bn_backward_tconv1(dy, weight, p, gamma, mean, rstd, relu, per_group, sync=None, beta=None, producer_bias_grad=None, dw_out=None):
     """Batch-norm backward fused with the data gradient of the ONE-output-channel 3x3x3 stride-1 transposed conv behind it
     (the decoder's last stage): dy [N][1][D+2][H+2][W+2], weight [C][1][3][3][3], p [N][C][D][H][W] -> dp (new tensor).
-    The C-channel gradient w.r.t. the normalised tensor is recomputed from dy in both passes and never stored.
-    Returns (dp, dgamma, dbeta) with the same conventions as bn_backward_."""
+    The C-channel gradient w.r.t. the normalised tensor is recomputed from dy and never stored.
+    `dw_out` (the conv weight's gradient buffer, accumulated into) selects the one-pass form: the conv's weight gradient is taken per
+    batch-norm group against the NORMALISED activation (vg_wgrad3d_grouped) and both the batch-norm reductions and dW follow from it
+    algebraically (vg_bn_tconv1_sums) -- the reduce pass over p and dy (0.35 ms at batch 64 / 8 covariates) disappears; the caller
+    must then NOT run the layer's ordinary weight gradient.  Returns (dp, dgamma, dbeta) with the conventions of bn_backward_."""
     lib = _lib.get_lib()
     N, C = p.shape[0], p.shape[1]
     ID, IH, IW = p.shape[2:]
@@ -425,7 +442,17 @@ def bn_backward_tconv1(dy, weight, p, gamma, mean, rstd, relu, per_group, sync=N
     P = ID * IH * IW
     ws = torch.empty(lib.size('vg_bn_tconv1_ws_bytes', N, C, ID, per_group) // 8, dtype=torch.float64, device=p.device)
     sums = torch.empty((G * C, 2), dtype=torch.float64, device=p.device)
-    _call(p, 'vg_bn_bwd_reduce_tconv1', _p(dy), _p(w), _p(p), N, C, ID, IH, IW, per_group, int(relu), _p(mean), _p(rstd), _p(ws), _p(sums))
+    if dw_out is not None:
+        assert dw_out.shape == weight.shape and dw_out.is_contiguous() and dw_out.dtype == torch.float32 and beta is not None
+        d = WgradDesc(N, C, 1, ID, IH, IW, ID + 2, IH + 2, IW + 2, 3, 3, 3, 1, 0, 0, 0, 0, int(relu), int(per_group))
+        nbytes = lib.size('vg_wgrad3d_grouped_ws_bytes', ctypes.byref(d))
+        wws = torch.empty(nbytes // 4, dtype=torch.float32, device=p.device)
+        q = torch.empty((G, C + 1, 27), dtype=torch.float32, device=p.device)
+        nshift = -(mean * rstd)
+        _call(p, 'vg_wgrad3d_grouped', ctypes.byref(d), _p(dy), _p(p), _p(rstd), _p(nshift), _p(wws), _p(q))
+        _call(p, 'vg_bn_tconv1_sums', _p(q), _p(w), _p(gamma), _p(beta), G, C, 27, _p(sums), _p(dw_out), 1)
+    else:
+        _call(p, 'vg_bn_bwd_reduce_tconv1', _p(dy), _p(w), _p(p), N, C, ID, IH, IW, per_group, int(relu), _p(mean), _p(rstd), _p(ws), _p(sums))
     count = float(per_group * P)
     local = None
     if sync is not None:
@@ -529,6 +556,13 @@ class BnConvAct(torch.autograd.Function):
         direct_db = bg is not None and not (ctx.input_is_data and ctx.has_bn)
         overlap = direct_db and wg is not None and not ctx.input_is_data
         skip_db = ctx.bias_grad_by_consumer            # the consuming layer's batch-norm backward already added it to bias.grad
+        # last decoder stage (one output channel, 3x3x3 stride-1 transposed conv behind a batch norm): batch-norm backward fused with
+        # the recomputed data gradient; with WGRAD_BN_SUMS its reductions AND dW come out of one grouped weight-gradient launch
+        fuse_last = FUSE_LAST_BN_BWD and ctx.has_bn and not ctx.input_is_data and spec.kind == 'convt' and spec.stride == 1 \
+            and spec.co == 1 and tuple(spec.k) == (3, 3, 3) and tuple(spec.pad) == (0, 0, 0) and spec.ci <= 16
+        dw_by_bn = fuse_last and WGRAD_BN_SUMS and _grouped_wgrad_ok(p_in.shape, per_group)
+        if dw_by_bn:
+            overlap = False
         if overlap:
             with on_side_stream(dy, dy, p_in, scale, shift, wg, bg):
                 if not skip_db:
@@ -555,7 +589,9 @@ class BnConvAct(torch.autograd.Function):
             else:
                 dw = conv_weight_grad(p_in, dy, spec, relu_in, None, None, per_group, out=wg)
             return None, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
-        if not overlap:
+        if dw_by_bn:
+            dw = None
+        elif not overlap:
             dw = conv_weight_grad(p_in, dy, spec, relu_in, scale, shift, per_group, out=wg)
         in_size = tuple(p_in.shape[2:])
         mmb = _mm_for(ctx.packed, weight, spec, 'bwd', tuple(dy.shape[2:]), in_size)
@@ -569,10 +605,12 @@ class BnConvAct(torch.autograd.Function):
                 if pb.grad is None:
                     pb.grad = torch.zeros_like(pb)
                 pbg = pb.grad
-            if FUSE_LAST_BN_BWD and spec.kind == 'convt' and spec.stride == 1 and spec.co == 1 and tuple(spec.k) == (3, 3, 3) \
-                    and tuple(spec.pad) == (0, 0, 0) and spec.ci <= 16:
-                # last decoder stage: the data gradient is recomputed inside the batch-norm backward passes, never stored
-                dp, dgamma, dbeta = bn_backward_tconv1(dy, weight, p_in, gamma, mean, rstd, relu_in, per_group, ctx.sync, beta, pbg)
+            if fuse_last:
+                # the data gradient is recomputed inside the batch-norm backward pass(es), never stored
+                dw_t = (wg if wg is not None else torch.zeros_like(weight)) if dw_by_bn else None
+                dp, dgamma, dbeta = bn_backward_tconv1(dy, weight, p_in, gamma, mean, rstd, relu_in, per_group, ctx.sync, beta, pbg, dw_out=dw_t)
+                if dw_by_bn and wg is None:
+                    dw = dw_t
             else:
                 dp = conv_mm(dy, mmb[0], mmb[1], None, False, None, None, 1, None) if mmb is not None else \
                     conv_backward_data(dy, wb, spec, in_size, None)
