@@ -74,12 +74,12 @@ bn_partial_k(const float* __restrict__ x, const float* __restrict__ p, const flo
 
 // one WAVE per (g,c): fold the chunk partials in a fixed order (lane-strided partial sums, then the shuffle tree);
 // nout = 3 writes [s0, s1, count], nout = 2 writes [s0, s1]
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(BN_THREADS)
 bn_fold_k(const double* __restrict__ part, int GC, int chunks, double count, int nout, double* __restrict__ sums) {
     const int i = blockIdx.x, lane = threadIdx.x;
     double a = 0, b = 0;
-    for (int k = lane; k < chunks; k += VG_WAVE) { a += part[((size_t)i * chunks + k) * 2]; b += part[((size_t)i * chunks + k) * 2 + 1]; }
-    a = wave_sum(a); b = wave_sum(b);
+    for (int k = lane; k < chunks; k += BN_THREADS) { a += part[((size_t)i * chunks + k) * 2]; b += part[((size_t)i * chunks + k) * 2 + 1]; }
+    block_sum2(a, b);
     if (lane == 0) {
         sums[(size_t)i * nout] = a; sums[(size_t)i * nout + 1] = b;
         if (nout == 3) sums[(size_t)i * nout + 2] = count;
@@ -102,15 +102,16 @@ __global__ void bn_finalize_k(const double* __restrict__ sums, int G, int C, con
     scale[i] = sc; shift[i] = bt - (float)mu * sc; mean[i] = (float)mu; rstd[i] = rs;
 }
 
-// fold + finalize in one launch (single-GPU path: nothing to all-reduce between them): one wavefront per (group, channel)
-__global__ void __launch_bounds__(64)
+// fold + finalize in one launch (single-GPU path: nothing to all-reduce between them): one block per (group, channel)
+// (256 threads: with one wavefront the ~1300 partials of a large layer were 21 dependent loads deep -- 16 us for 72 numbers)
+__global__ void __launch_bounds__(BN_THREADS)
 bn_fold_finalize_k(const double* __restrict__ part, int C, int chunks, double count, const float* __restrict__ gamma,
                    const float* __restrict__ beta, float eps, float* __restrict__ scale, float* __restrict__ shift,
                    float* __restrict__ mean, float* __restrict__ rstd) {
     const int i = blockIdx.x, lane = threadIdx.x;
     double a = 0, b = 0;
-    for (int k = lane; k < chunks; k += VG_WAVE) { a += part[((size_t)i * chunks + k) * 2]; b += part[((size_t)i * chunks + k) * 2 + 1]; }
-    a = wave_sum(a); b = wave_sum(b);
+    for (int k = lane; k < chunks; k += BN_THREADS) { a += part[((size_t)i * chunks + k) * 2]; b += part[((size_t)i * chunks + k) * 2 + 1]; }
+    block_sum2(a, b);
     if (lane == 0) {
         const int c = i % C;
         const double mu = a / count;
@@ -161,13 +162,13 @@ bn_bwd_apply_k(float* __restrict__ dxe, const float* __restrict__ p, int C, long
 }
 
 // out[c] (+)= sum over groups and chunks of part[(g*C + c)*chunks + k]
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(BN_THREADS)
 csum_fold_k(const double* __restrict__ part, int G, int C, int chunks, int accumulate, float* __restrict__ out) {
     const int c = blockIdx.x, lane = threadIdx.x;
-    double a = 0;
+    double a = 0, unused = 0;
     for (int g = 0; g < G; ++g)
-        for (int k = lane; k < chunks; k += VG_WAVE) a += part[((size_t)g * C + c) * chunks + k];
-    a = wave_sum(a);
+        for (int k = lane; k < chunks; k += BN_THREADS) a += part[((size_t)g * C + c) * chunks + k];
+    block_sum2(a, unused);
     if (lane == 0) out[c] = (accumulate ? out[c] : 0.f) + (float)a;
 }
 
@@ -230,11 +231,11 @@ extern "C" int vg_bn_stats(const float* x, int32_t N, int32_t C, int64_t P, int3
     if ((rc = vg_check_launch("bn_partial"))) return rc;
     if (!ext_sums) {
         if (!scale || !shift || !mean || !rstd) { vg_set_error("vg_bn_stats: null output"); return VG_ERR_ARG; }
-        vg_launch(bn_fold_finalize_k, dim3(G * C), dim3(64), 0, s, (const double*)part, (int)C, chunks, (double)total, gamma, beta, eps,
+        vg_launch(bn_fold_finalize_k, dim3(G * C), dim3(BN_THREADS), 0, s, (const double*)part, (int)C, chunks, (double)total, gamma, beta, eps,
                   scale, shift, mean, rstd);
         return vg_check_launch("bn_fold_finalize");
     }
-    vg_launch(bn_fold_k, dim3(G * C), dim3(64), 0, s, (const double*)part, G * C, chunks, (double)total, 3, sums);
+    vg_launch(bn_fold_k, dim3(G * C), dim3(BN_THREADS), 0, s, (const double*)part, G * C, chunks, (double)total, 3, sums);
     return vg_check_launch("bn_fold");                // caller all-reduces, then calls vg_bn_finalize
 }
 
@@ -252,7 +253,7 @@ extern "C" int vg_bn_bwd_reduce(const float* dxe, const float* p, int32_t N, int
     vg_launch(bn_partial_k<1>, dim3(chunks, C, G), dim3(BN_THREADS), 0, s, dxe, p, mean, rstd, (int)C, (long long)P,
               (int)per_group, (int)relu, pl.cp, part);
     if ((rc = vg_check_launch("bn_bwd_partial"))) return rc;
-    vg_launch(bn_fold_k, dim3(G * C), dim3(64), 0, s, (const double*)part, G * C, chunks, (double)total, 2, sums);
+    vg_launch(bn_fold_k, dim3(G * C), dim3(BN_THREADS), 0, s, (const double*)part, G * C, chunks, (double)total, 2, sums);
     return vg_check_launch("bn_bwd_fold");
 }
 
@@ -271,7 +272,7 @@ extern "C" int vg_bn_bwd_apply(float* dxe, const float* p, int32_t N, int32_t C,
               (int)per_group, (int)relu, gamma, mean, rstd, sums, count, pl.cp, dgamma_part, dbeta_part, csum_part);
     if ((rc = vg_check_launch("bn_bwd_apply"))) return rc;
     if (chsum) {
-        vg_launch(csum_fold_k, dim3(C), dim3(64), 0, (hipStream_t)stream, (const double*)csum_part, G, (int)C, pl.chunks(),
+        vg_launch(csum_fold_k, dim3(C), dim3(BN_THREADS), 0, (hipStream_t)stream, (const double*)csum_part, G, (int)C, pl.chunks(),
                   (int)chsum_accumulate, chsum);
         return vg_check_launch("bn_bwd csum_fold");
     }
@@ -500,7 +501,7 @@ extern "C" int vg_bn_bwd_reduce_tconv1(const float* dy, const float* w, const fl
         vg_launch(bn_tconv1_k<0, 0>, dim3(a.tilesD, N), dim3(BN_THREADS), shmem, s, dy, w, p, (float*)nullptr, (const float*)nullptr, mean, rstd,
                   (const double*)nullptr, 1.0, a, part, (double*)nullptr);
     if ((rc = vg_check_launch("bn_bwd_reduce_tconv1"))) return rc;
-    vg_launch(bn_fold_k, dim3(G * C), dim3(64), 0, s, (const double*)part, G * C, chunks, (double)per_group * ID * IH * IW, 2, sums);
+    vg_launch(bn_fold_k, dim3(G * C), dim3(BN_THREADS), 0, s, (const double*)part, G * C, chunks, (double)per_group * ID * IH * IW, 2, sums);
     return vg_check_launch("bn_bwd_reduce_tconv1 fold");
 }
 
@@ -557,19 +558,19 @@ extern "C" int vg_bn_bwd_apply_tconv1(const float* dy, const float* w, const flo
                   (double*)nullptr, csum_part);
     if ((rc = vg_check_launch("bn_bwd_apply_tconv1"))) return rc;
     if (chsum) {
-        vg_launch(csum_fold_k, dim3(C), dim3(64), 0, s, (const double*)csum_part, G, (int)C, chunks, (int)chsum_accumulate, chsum);
+        vg_launch(csum_fold_k, dim3(C), dim3(BN_THREADS), 0, s, (const double*)csum_part, G, (int)C, chunks, (int)chsum_accumulate, chsum);
         return vg_check_launch("bn_bwd_apply_tconv1 csum_fold");
     }
     return VG_OK;
 }
 
 namespace {
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(BN_THREADS)
 chsum_fold_k(const double* __restrict__ part, int C, int chunks, int accumulate, float* __restrict__ out) {
     const int c = blockIdx.x, lane = threadIdx.x;
-    double a = 0;
-    for (int k = lane; k < chunks; k += VG_WAVE) a += part[((size_t)c * chunks + k) * 2];
-    a = wave_sum(a);
+    double a = 0, unused = 0;
+    for (int k = lane; k < chunks; k += BN_THREADS) a += part[((size_t)c * chunks + k) * 2];
+    block_sum2(a, unused);
     if (lane == 0) out[c] = (accumulate ? out[c] : 0.f) + (float)a;
 }
 }  // namespace
@@ -586,7 +587,7 @@ extern "C" int vg_channel_sum(const float* x, int32_t N, int32_t C, int64_t P, v
     vg_launch(bn_partial_k<0>, dim3(chunks, C, 1), dim3(BN_THREADS), 0, s, x, (const float*)nullptr, (const float*)nullptr,
               (const float*)nullptr, (int)C, (long long)P, (int)N, 0, pl.cp, part);
     if ((rc = vg_check_launch("channel_sum partial"))) return rc;
-    vg_launch(chsum_fold_k, dim3(C), dim3(64), 0, s, (const double*)part, (int)C, chunks, (int)accumulate, out);
+    vg_launch(chsum_fold_k, dim3(C), dim3(BN_THREADS), 0, s, (const double*)part, (int)C, chunks, (int)accumulate, out);
     return vg_check_launch("channel_sum fold");
 }
 
@@ -597,10 +598,10 @@ extern "C" int vg_bn_stats_from_parts(const double* part, int32_t G, int32_t C, 
     hipStream_t s = (hipStream_t)stream;
     if (!ext_sums) {
         if (!scale || !shift || !mean || !rstd) { vg_set_error("vg_bn_stats_from_parts: null output"); return VG_ERR_ARG; }
-        vg_launch(bn_fold_finalize_k, dim3(G * C), dim3(64), 0, s, part, (int)C, (int)chunks, count, gamma, beta, eps, scale, shift, mean, rstd);
+        vg_launch(bn_fold_finalize_k, dim3(G * C), dim3(BN_THREADS), 0, s, part, (int)C, (int)chunks, count, gamma, beta, eps, scale, shift, mean, rstd);
         return vg_check_launch("bn_fold_finalize(parts)");
     }
-    vg_launch(bn_fold_k, dim3(G * C), dim3(64), 0, s, part, G * C, (int)chunks, count, 3, ext_sums);
+    vg_launch(bn_fold_k, dim3(G * C), dim3(BN_THREADS), 0, s, part, G * C, (int)chunks, count, 3, ext_sums);
     return vg_check_launch("bn_fold(parts)");
 }
 

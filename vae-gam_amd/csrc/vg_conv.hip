@@ -470,7 +470,7 @@ int launch_corr_plane(const vg_conv_desc* d, const float* x, const float* wpk, c
     // loss where it doubles a 25 KB slot (convt5 forward 244 -> 341 us: only two 52 KB blocks fit a CU). Off by default.
     static const int nbuf_env = getenv("VG_PLANE_NBUF") ? atoi(getenv("VG_PLANE_NBUF")) : 0;
     const size_t budget2 = (TDt * THt * TW > 16 ? 78 : 52) * 1024;      // two blocks per CU there (registers), three otherwise
-    p.nbuf = (nbuf_env == 2 && d->CI > 1 && 2 * (size_t)p.ch_floats * sizeof(float) + (PLANE_SLACK + 64) * sizeof(float) <= budget2) ? 2 : 1;
+    p.nbuf = ((nbuf_env == 2 || TDt * THt * TW > 16) && d->CI > 1 && 2 * (size_t)p.ch_floats * sizeof(float) + (PLANE_SLACK + 64) * sizeof(float) <= budget2) ? 2 : 1;
     const size_t bud = p.nbuf == 2 ? budget2 : budget;
     int cch = (int)((bud - (PLANE_SLACK + 64) * sizeof(float)) / ((size_t)p.ch_floats * sizeof(float) * p.nbuf));
     if (cch < 1) cch = 1;
@@ -947,7 +947,9 @@ extern "C" int vg_corr3d(const vg_conv_desc* d, const float* x, const float* wpk
     if (d->KD == 4 && d->KH == 4 && d->KW == 4 && d->stride == 2) CORR_MFMA(4, 4, 4, 2)
 #undef CORR_MFMA
     if (k333 && d->stride == 1) {
-        if (d->CO == 1 && getenv("VG_C5_TDT4")) CORR_LDS(1, 3, 3, 3, 1, 4, 2, 4);
+        // one output channel (the decoder's last layer): 4x2x4 outputs per thread, 6 input planes per 4 output planes (input fetched
+        // 1.5x instead of 2x), two blocks per CU with the next channel's planes in flight: 803 -> 735 us at batch 64 / 8 covariates
+        if (d->CO == 1 && !getenv("VG_C5_TDT2")) CORR_LDS(1, 3, 3, 3, 1, 4, 2, 4);
         if (d->CO == 1) CORR_LDS(1, 3, 3, 3, 1, 2, 2, 4);
         if (d->CO % 8 == 0 && !small) CORR_LDS_RT(8, 3, 3, 3, 1, 1, 1, 4);
         if (d->CO % 4 == 0 && small) CORR(4, 3, 3, 3, 1, 1, 1, 2);
