@@ -146,6 +146,10 @@ def main():
         dp = dpmod.DataParallelContext.from_env()
 
     B, C = a.batch, a.covariates
+    # weak scaling: 2 synthetic subjects per GPU (configs[3]: 16 subjects on 8 GPUs), and always at least two global minibatches
+    a.subjects = max(a.subjects, 2 * world)
+    while a.subjects * 98 < 2 * B * world:
+        a.subjects += 1
     ds = synthetic.make_dataset(num_subjects=a.subjects, vols_per_subject=98, num_covariates=C, seed=0)
     torch.manual_seed(1)                                             # CLI default seed (multsubj_reg_run_GP.py:31)
     model = VAE(num_covariates=C, glm_maps=ds['glm'], xu_ranges=ds['xu_ranges'], device_name='cuda', data_parallel=dp)

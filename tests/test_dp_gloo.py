@@ -35,19 +35,26 @@ def _single_process_reference():
     return float(loss), g32['g'].clone(), g32['p'].clone(), model.epsilon.detach().clone()
 
 
-def _rank_main(rank, world, port, out_dir):
+def _rank_main(rank, world, port, out_dir, dp_gain='global'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     torch.set_num_threads(2)
     from vae_gam_amd import dp as dpmod
     T.load_emu_library()
     ctx = dpmod.DataParallelContext.from_env(backend='gloo')
     x, cov, xu, glm = T.make_inputs(B_GLOBAL, C, seed=11)
-    model = T.make_model(C, xu, glm, dp=ctx)
+    model = T.make_model(C, xu, glm, dp=ctx, dp_gain=dp_gain)
     b = B_GLOBAL // world
     sl = slice(rank * b, (rank + 1) * b)
     loss = model.train_step(torch.zeros(b, dtype=torch.int64), cov[sl], x[sl])          # noise: the shared seeded generator
     g32 = model.optimizer.groups[torch.float32]
-    torch.save({'loss': float(loss), 'g': g32['g'].clone(), 'p': g32['p'].clone(), 'eps': model.epsilon.detach().clone()},
+    extra = {}
+    if dp_gain == 'local':                                       # the gains this rank drew for its slice (a fresh forward, same noise tape)
+        gen = torch.Generator().manual_seed(1234)
+        noise = {'eps_w': torch.randn(B_GLOBAL, 1, generator=gen), 'eps_d': torch.randn(B_GLOBAL, 32, generator=gen),
+                 'eps_beta': torch.randn(C, B_GLOBAL, generator=gen)}
+        with torch.no_grad():
+            extra['task_var'] = model.forward_core(cov[sl], x[sl], noise=noise)['task_var'].clone()
+    torch.save({'loss': float(loss), 'g': g32['g'].clone(), 'p': g32['p'].clone(), 'eps': model.epsilon.detach().clone(), **extra},
                os.path.join(out_dir, 'rank%d.pt' % rank))
     ctx.shutdown()
 
@@ -72,6 +79,30 @@ def test_two_ranks_equal_one_rank_global_batch(tmp_path):
     assert torch.equal(outs[0]['p'], outs[1]['p'])                  # replicas stay identical
     moved = (ref_p - outs[0]['p']).abs()
     assert float(moved.max()) <= 2.1e-3                             # differences only where a near-zero gradient changed sign
+
+
+def test_local_gain_mode_draws_each_ranks_slice_from_its_own_covariance(tmp_path):
+    """dp_gain='local' (the default under data parallelism): a rank's gains are what ONE process draws for that rank's slice alone
+    (its own B x B gain covariance, its columns of the noise tape) -- no all-gather, cost independent of the number of ranks --
+    while batch-norm statistics, the loss normalisation and the gradient sum stay global: replicas remain identical."""
+    port = _free_port()
+    mp.spawn(_rank_main, args=(2, port, str(tmp_path), 'local'), nprocs=2, join=True)
+    outs = [torch.load(os.path.join(tmp_path, 'rank%d.pt' % r)) for r in range(2)]
+    assert torch.equal(outs[0]['p'], outs[1]['p']) and torch.equal(outs[0]['g'], outs[1]['g'])
+    T.load_emu_library()
+    x, cov, xu, glm = T.make_inputs(B_GLOBAL, C, seed=11)
+    model = T.make_model(C, xu, glm)                             # same seed: the parameters the ranks started from
+    gen = torch.Generator().manual_seed(1234)
+    torch.randn(B_GLOBAL, 1, generator=gen); torch.randn(B_GLOBAL, 32, generator=gen)
+    eps_beta = torch.randn(C, B_GLOBAL, generator=gen)
+    b = B_GLOBAL // 2
+    for r in range(2):
+        sl = slice(r * b, (r + 1) * b)
+        # the ranks evaluated their gains AFTER one optimiser step: bring the single-process model to the same parameters
+        model.optimizer.groups[torch.float32]['p'].copy_(outs[r]['p'])
+        with torch.no_grad():
+            tv = model._gains(cov[sl][:, :C].float(), eps_beta[:, sl].contiguous())[0]
+        np.testing.assert_allclose(outs[r]['task_var'].numpy(), tv.numpy(), rtol=1e-6, atol=1e-7)
 
 
 def test_device_resident_data_shards_every_global_batch():

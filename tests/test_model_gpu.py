@@ -348,7 +348,7 @@ def _dp_rank(rank, world, port, out_dir):
     ctx = dpmod.DataParallelContext.from_env(backend='gloo')          # one GPU on this box: collectives staged through the host
     ds = synthetic.make_dataset(num_subjects=1, vols_per_subject=16, num_covariates=3, seed=6)
     torch.manual_seed(1)
-    model = VAE(num_covariates=3, glm_maps=ds['glm'], xu_ranges=ds['xu_ranges'], device_name='cuda', data_parallel=ctx)
+    model = VAE(num_covariates=3, glm_maps=ds['glm'], xu_ranges=ds['xu_ranges'], device_name='cuda', data_parallel=ctx, dp_gain='global')
     Bg = 8; b = Bg // world
     x = torch.from_numpy(ds['volumes'][rank * b:(rank + 1) * b]).cuda(); cov = torch.from_numpy(ds['covariates'][rank * b:(rank + 1) * b]).cuda()
     loss = model.train_step(torch.zeros(b, dtype=torch.int64, device='cuda'), cov, x)
@@ -451,7 +451,7 @@ def test_cli_trains_then_exports_like_the_reference_wrapper(tmp_path):
 def _cli_rank(rank, world, port, argv, out_file):
     import os
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
-                      HSA_ENABLE_IPC_MODE_LEGACY='0', VG_DP_BACKEND='gloo', VG_DP_FORCE='1')
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', VG_DP_BACKEND='gloo', VG_DP_FORCE='1', VG_DP_GAIN='global')
     from vae_gam_amd import multsubj_reg_run_GP as cli
     m = cli.main(argv)
     if rank == 0:

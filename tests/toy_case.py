@@ -32,6 +32,6 @@ def make_inputs(B, C, seed=0):
     return torch.from_numpy(x), torch.from_numpy(cov), xu, glm
 
 
-def make_model(C, xu, glm, dp=None, seed=1):
+def make_model(C, xu, glm, dp=None, seed=1, dp_gain='global'):
     torch.manual_seed(seed)
-    return VAE(num_covariates=C, glm_maps=glm, xu_ranges=xu, device_name='cpu', img_shape=IMG, data_parallel=dp)
+    return VAE(num_covariates=C, glm_maps=glm, xu_ranges=xu, device_name='cpu', img_shape=IMG, data_parallel=dp, dp_gain=dp_gain)

@@ -739,10 +739,9 @@ struct WgradRowsParams {
     int lds_floats;
     int items;
     int wave_slabs;             // small grids: every wave writes its own slab (no cross-wave LDS reduction: 4 serial rounds, ~13 us)
-    // grouped mode (vg_wgrad3d_grouped): a block owns a CONTIGUOUS range of ipb items and closes a slab whenever the batch-norm group
-    // (sample / per_group) changes inside it -- at most once (ipb <= grp_items) -- so every slab belongs to one group: two slabs per block
-    int grp_items;              // items per group (0: plain mode, round-robin items, one slab per block)
-    int ipb;                    // items per block
+    // grouped mode (vg_wgrad3d_grouped, template GRP): the grid is split evenly over the batch-norm groups (sample / per_group)
+    int grp_items;              // items per group
+    int ipb;                    // blocks per group
     int ones_row;               // 1: MFMA row CB carries a constant-one position channel -> per-tap sums of the window tensor
 };
 
@@ -823,21 +822,14 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
             if (cb < CBW && tap < KVOL) out[(size_t)cb * ncol_o + ca * KVOL + tap] = red[i];
         }
     };
-    // plain mode: one segment, items blockIdx.x, +gridDim.x, ...; grouped mode: two segments, the block's contiguous item range split
-    // at the group boundary inside it (the second one empty if there is none) -- ONE copy of the loop body and of the slab write-out
-    // (GRP is a template parameter: the segment loop costs the plain instances ~50 VGPRs -- one wave per SIMD less -- if it is a run-time mode)
-    const int it_step = GRP ? 1 : (int)gridDim.x;
-    const int it0 = GRP ? (int)blockIdx.x * p.ipb : (int)blockIdx.x;
-    const int it1 = GRP ? min(it0 + p.ipb, p.items) : p.items;
-    const int split = GRP ? min((it0 / p.grp_items + 1) * p.grp_items, it1) : it1;
-    constexpr int nseg = GRP ? 2 : 1;
+    // plain mode: items blockIdx.x, +gridDim.x, ...   grouped mode: the grid is split evenly over the batch-norm groups (ipb = blocks per
+    // group); a group's blocks deal ITS items round-robin, so every slab belongs to one group and blocks running side by side still
+    // work on neighbouring tiles (their halos meet in L2; contiguous item ranges per block cost 0.2 ms in re-fetched planes)
+    const int it_step = GRP ? p.ipb : (int)gridDim.x;
+    const int it0 = GRP ? ((int)blockIdx.x / p.ipb) * p.grp_items + (int)blockIdx.x % p.ipb : (int)blockIdx.x;
+    const int it1 = GRP ? ((int)blockIdx.x / p.ipb + 1) * p.grp_items : p.items;
 
-    for (int seg = 0; seg < nseg; ++seg) {
-    if (GRP) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { acc[t].v[0] = 0.f; acc[t].v[1] = 0.f; acc[t].v[2] = 0.f; acc[t].v[3] = 0.f; }
-    }
-    for (int item = seg ? split : it0; item < (seg || !GRP ? it1 : split); item += it_step) {
+    for (int item = it0; item < it1; item += it_step) {
         const int n = item / (p.pdblocks * p.nph); const int rem = item % (p.pdblocks * p.nph);
         const int pd0 = (rem / p.nph) * p.TPD, ph0 = (rem % p.nph) * p.TPH;
         const int nrow = min(p.TPH, d.PH - ph0), ndz = min(p.TPD, d.PD - pd0);
@@ -964,26 +956,18 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
             });
         }
     }
-    write_out((int)blockIdx.x * nseg + seg);
-    }
+    write_out((int)blockIdx.x);
 }
 
-// Slabs of a grouped launch -> out[g][len].  Block (i-chunk, g) walks the blocks whose item range touches group g; of their two
-// slabs it takes those that belong to g (slab 0: the group of the block's first item, slab 1: of its last item).
+// Slabs of a grouped launch -> out[g][len]: group g owns the slabs [g*spg, (g+1)*spg)
 __global__ void __launch_bounds__(64 * SLAB_ROWS)
-slab_sum_groups_k(const float* __restrict__ ws, int nblocks, int per_slab, int len, int ipb, int grp_items, int items,
-                  float* __restrict__ out) {
+slab_sum_groups_k(const float* __restrict__ ws, int spg, int len, float* __restrict__ out) {
     __shared__ float red[SLAB_ROWS][64];
     const int j = threadIdx.x % 64, r = threadIdx.x / 64;
     const int i = blockIdx.x * 64 + j, g = blockIdx.y;
-    const int b_lo = (g * grp_items) / ipb, b_hi = min(((g + 1) * grp_items - 1) / ipb, nblocks - 1);
     float s0 = 0.f;
     if (i < len)
-        for (int k = b_lo * 2 * per_slab + r; k < (b_hi + 1) * 2 * per_slab; k += SLAB_ROWS) {
-            const int bs = k / per_slab, blk = bs >> 1, sg = bs & 1;
-            const int first = blk * ipb, last = min(first + ipb, items) - 1;
-            if ((sg ? last : first) / grp_items == g) s0 += ws[(size_t)k * len + i];
-        }
+        for (int k = g * spg + r; k < (g + 1) * spg; k += SLAB_ROWS) s0 += ws[(size_t)k * len + i];
     red[r][j] = s0;
     __syncthreads();
     if (r == 0 && i < len) {
@@ -1073,25 +1057,25 @@ int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const fl
     int grid = 256 * per_cu; if (grid > p.items) grid = p.items;
     p.grp_items = 0; p.ipb = 0; p.ones_row = 0;
     if (grouped) {
-        // per-group partials (+ the ones row): contiguous item ranges, at most one group boundary per block
+        // per-group partials (+ the ones row): the same number of blocks for every group
         if (d->CB >= 16) return -1;                                    // the ones row needs a free MFMA row
+        const int G = d->N / d->per_group;
         p.grp_items = d->per_group * p.pdblocks * p.nph; p.ones_row = 1;
-        p.ipb = vg_cdiv(p.items, grid);
+        p.ipb = grid / G; if (p.ipb < 1) p.ipb = 1;
         if (p.ipb > p.grp_items) p.ipb = p.grp_items;
-        grid = vg_cdiv(p.items, p.ipb);
+        grid = p.ipb * G;
     }
     const int len = (d->CB + p.ones_row) * CA * KVOL;
     p.wave_slabs = grid <= 512 ? 1 : 0;
     const int per_slab = p.wave_slabs ? 4 : 1;
-    const int nslabs = grid * per_slab * (grouped ? 2 : 1);
+    const int nslabs = grid * per_slab;
     if (ws_bytes_only) { *ws_bytes_only = (int64_t)nslabs * len * sizeof(float); return VG_OK; }
     vg_launch(kern, dim3(grid), dim3(256), fl * sizeof(float), s, a, b, in_scale, in_shift, ws, p);
     int rc = vg_check_launch("wgrad_rows");
     if (rc) return rc;
     if (grouped) {
         const int G = d->N / d->per_group;
-        vg_launch(slab_sum_groups_k, dim3(vg_cdiv(len, 64), G), dim3(64 * SLAB_ROWS), 0, s, (const float*)ws, grid, per_slab, len,
-                  p.ipb, p.grp_items, p.items, dw);
+        vg_launch(slab_sum_groups_k, dim3(vg_cdiv(len, 64), G), dim3(64 * SLAB_ROWS), 0, s, (const float*)ws, p.ipb * per_slab, len, dw);
         return vg_check_launch("wgrad slab_sum_groups");
     }
     vg_launch(slab_sum_k, dim3(vg_cdiv(len, 64)), dim3(64 * SLAB_ROWS), 0, s, (const float*)ws, nslabs, len, accumulate, dw);

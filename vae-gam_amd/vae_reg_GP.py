@@ -87,14 +87,18 @@ class VAE(nn.Module):
     def __init__(self, nf=8, save_dir='', lr=1e-3, num_covariates=8, num_latents=32, device_name="auto",
                  num_inducing_pts=6, gp_kl_scale=10.0, glm_maps='', glm_reg_scale=1.0, csv_files='',
                  neural_covariates=True, *, img_shape=IMG_SHAPE, xu_ranges=None, tensorboard=False,
-                 data_parallel=None, gp_jitter=0.0):
+                 data_parallel=None, gp_jitter=0.0, dp_gain='local'):
         """Arguments up to `neural_covariates` are the reference's (vae_reg_GP.py:36-37).
         Keyword-only extensions: `img_shape` (41x49x35 or 82x98x70), `xu_ranges` (inducing-point
         ranges given directly instead of read from `csv_files`), `tensorboard` (off by default),
         `data_parallel` (a dp.DataParallelContext), `gp_jitter` (0 = the reference's plain inverse of the
         inducing-point kernel matrix Ku, gp.py:104-107; > 0: Ku + gp_jitter*I on the unit-variance scale, i.e. the
         inducing prior k_var*(Ku + jitter I), factorised by Cholesky -- needed where the inducing grid is dense against the
-        length scale and Ku is singular in any precision, e.g. 64 points).  `glm_maps` may be a CSV path
+        length scale and Ku is singular in any precision, e.g. 64 points).  `dp_gain` (data parallel only):
+        'local' = every rank draws the gains of ITS slice of the minibatch from that slice's own B x B gain covariance (cost
+        independent of the number of ranks; same per-volume marginals, hence the same expected loss and gradient, as the global
+        draw), 'global' = the gains of the whole global minibatch are drawn jointly on every rank (bit-for-bit the one-process
+        global-batch step, but O(B_global^2..3) serial work per rank).  `glm_maps` may be a CSV path
         (reference) or an array of shape (V, C+1) whose column 0 is the CSV index column."""
         super(VAE, self).__init__()
         self.nf, self.save_dir, self.lr = nf, save_dir, lr
@@ -107,6 +111,8 @@ class VAE(nn.Module):
         self.geom = net_geometry(self.img_shape, nf)
         self.schema = covariate_schema(num_covariates, neural_covariates)
         self.dp = data_parallel
+        assert dp_gain in ('local', 'global')
+        self.dp_gain = dp_gain
         assert device_name != "cuda" or torch.cuda.is_available()
         if device_name == "auto":
             device_name = "cuda" if torch.cuda.is_available() else "cpu"
@@ -430,12 +436,16 @@ class VAE(nn.Module):
         self._packed.refresh()                       # one launch: every conv weight -> the images the kernels read
         # data parallel: this rank holds rows [lo, lo+B) of a global batch of Bg = world*B volumes
         W, lo, Bg = 1, 0, B
+        joint_gains = False
         if self.dp is not None:
             W = self.dp.world_size; lo = self.dp.rank * B; Bg = W * B
-            covariates = self.dp.all_gather_rows(covariates)                                # (Bg, C): the gains couple the batch
+            joint_gains = self.dp_gain == 'global' and W > 1
+            if joint_gains:
+                covariates = self.dp.all_gather_rows(covariates)                            # (Bg, C): the gains couple the batch
         if noise is None:
             noise = self.draw_noise(Bg, dev)
         eps_w, eps_d = noise['eps_w'][lo:lo + B], noise['eps_d'][lo:lo + B]
+        eps_beta = noise['eps_beta'] if (joint_gains or W == 1) else noise['eps_beta'][:, lo:lo + B].contiguous()
         # The gain block (one launch forward, one backward; a single workgroup per covariate walking B serial Cholesky /
         # substitution steps) depends only on the covariates and the gain parameters: it is queued on a second HIP stream
         # beside the encoder/decoder (autograd replays its backward on that stream too, beside the decoder's backward), and
@@ -445,9 +455,9 @@ class VAE(nn.Module):
             main = torch.cuda.current_stream(dev)
             gains_stream.wait_stream(main)
             with torch.cuda.stream(gains_stream):
-                gains = self._gains(covariates, noise['eps_beta'], join_stream=main)
+                gains = self._gains(covariates, eps_beta, join_stream=main)
         else:
-            gains = self._gains(covariates, noise['eps_beta'])
+            gains = self._gains(covariates, eps_beta)
         heads = self._encode_heads(x, stacked=True)
         G = C + 1
         # d = exp(a) + 1e-6*[any(d < 1e-6)] (:321-323, no sync), z = rsample (:325), kl_z (:400) and the G decoder
@@ -465,7 +475,7 @@ class VAE(nn.Module):
             torch.cuda.current_stream(dev).wait_stream(gains_stream)
             for t in (task_var, gp_kl_loss):
                 t.record_stream(torch.cuda.current_stream(dev))
-        if W > 1:
+        if joint_gains:
             task_var = task_var[:, lo:lo + B].contiguous()                                  # full-batch gains, this rank's columns
         xf = x.reshape(B, self.img_dim)
         slp, dist = ops.GamElbo.apply(logits, task_var, xf, self.epsilon.view(-1), self._glm())
@@ -556,6 +566,8 @@ class VAE(nn.Module):
         torch.cuda.current_stream(x.device).synchronize()       # everything queued so far has used the device-side count
         rng = torch.cuda.get_rng_state(x.device)
         try:
+            if self.dp is not None and self.dp._host_staging:
+                raise RuntimeError('collectives staged through the host (gloo) cannot be captured')
             st['noise'] = self.draw_noise(x.shape[0] * (1 if self.dp is None else self.dp.world_size), x.device)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -565,7 +577,15 @@ class VAE(nn.Module):
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                st['loss'] = self._train_step_eager(st['ids'], st['cov'], st['x'], noise=st['noise'])
+                try:
+                    st['loss'] = self._train_step_eager(st['ids'], st['cov'], st['x'], noise=st['noise'])
+                except Exception:
+                    # every stream forked into the capture must be joined before it can end, or the capture stays open and
+                    # poisons every later launch of this process
+                    cur = torch.cuda.current_stream(x.device)
+                    for s_ in list(self._gain_streams.values()) + list(ops._SIDE.values()):
+                        cur.wait_stream(s_)
+                    raise
             for g, p0, m0, v0 in snap:
                 g['p'].copy_(p0); g['m'].copy_(m0); g['v'].copy_(v0)
             self.optimizer.set_step_count(step0)
