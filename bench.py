@@ -103,7 +103,7 @@ def alg_bytes_per_launch(key, model, B):
         has_mask = direction == 'bwd' and lname not in ('convt1', 'convt3', 'convt5', 'conv3', 'conv5')
         extra = n_in if has_mask else 0                       # data gradient of a layer fed by a plain ReLU: + the saved activation (mask)
         return 4 * (n_in + n_out + extra)
-    if fn == 'vg_wgrad3d':
+    if fn in ('vg_wgrad3d', 'vg_wgrad3d_grouped'):
         return 4 * (n_in + n_out)
     return None
 

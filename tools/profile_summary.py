@@ -64,10 +64,9 @@ if out:
     # keyed the way bench.py names its kernels (entry point : layer / direction): the decoder launch (largest traffic) of each instance
     TABLE = {'vg_tconv3d_s2_stats:convt4/fwd': r'tconv3d_s2_k<8, 5, 3, 3', 'vg_conv_mm:convt4/fwd': r'conv_mm_k<4, ', 'vg_conv_mm:convt3/fwd': r'conv_mm_k<1, 6, 9',
              'vg_conv_mm:convt3/bwd': r'conv_mm_k<1, 8, 7', 'vg_corr3d:convt4/bwd': r'corr3d_plane_k<8, 5, 3, 3, 2',
-             'vg_corr3d:convt5/fwd': r'corr3d_plane_k<1, 3, 3, 3, 1, 2, 2, 4', 'vg_corr3d:convt3/fwd': r'corr3d_plane_k<8, 3, 3, 3, 1, 1, 1, 4',
-             'vg_wgrad3d:convt5/bwd': r'wgrad_rows_k<1, 2, 3, 3, 3, 1', 'vg_wgrad3d:convt4/bwd': r'wgrad_rows_k<8, 3, 5, 3, 3, 2',
-             'vg_wgrad3d:convt3/bwd': r'wgrad_rows_k<8, 2, 3, 3, 3, 1', 'vg_bn_bwd_reduce_tconv1:convt5/bwd': r'bn_tconv1_k<0, 8>',
-             'vg_bn_bwd_apply_tconv1:convt5/bwd': r'bn_tconv1_k<1, 8>'}
+             'vg_corr3d:convt5/fwd': r'corr3d_plane_k<1, 3, 3, 3, 1, 4, 2, 4', 'vg_corr3d:convt3/fwd': r'corr3d_plane_k<8, 3, 3, 3, 1, 1, 1, 4',
+             'vg_wgrad3d_grouped:convt5/bwd': r'wgrad_rows_k<1, 2, 3, 3, 3, 1', 'vg_wgrad3d:convt4/bwd': r'wgrad_rows_k<8, 3, 5, 3, 3, 2',
+             'vg_wgrad3d:convt3/bwd': r'wgrad_rows_k<8, 2, 3, 3, 3, 1', 'vg_bn_bwd_apply_tconv1:convt5/bwd': r'bn_tconv1_k<1, 8>'}
     by_layer = {}
     for key, sub in TABLE.items():
         cands = [v for k, v in out.items() if sub in k]

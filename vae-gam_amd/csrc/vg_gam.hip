@@ -100,57 +100,60 @@ gam_fwd_fold_k(const float* __restrict__ part_slp, const float* __restrict__ par
 }
 
 // backward.  grid (vblocks, BS): block handles voxels [vb*GT, +GT) and samples b = bs, bs+BS, ...
-//   part_dsig[bs][v], part_dgain[i][b][vb]
+//   part_dsig[bs][v], part_dgain[i][b][vb*4 + wave]
+// Every logit is read ONCE and its sigmoid kept in a register for the second pass (CMAX = compile-time bound of the covariate
+// loop, fully unrolled); the per-(covariate, sample) sums of d gain leave the block as one partial per WAVE, so the sample loop has
+// no barrier at all (the first version re-read and re-evaluated all C+1 sigmoids and paid two __syncthreads per covariate and
+// sample: 228 us at batch 64 / 8 covariates against 60 us of HBM time).
+template <int CMAX>
 __global__ void __launch_bounds__(GT)
 gam_bwd_k(const float* __restrict__ logits, const float* __restrict__ gain, const float* __restrict__ x,
           const double* __restrict__ eps, const float* __restrict__ glm, const float* __restrict__ dist,
           const float* __restrict__ g_slp, const float* __restrict__ g_dist, int C, int B, long long V,
           float* __restrict__ d_logits, float* __restrict__ part_dsig, float* __restrict__ part_dgain) {
-    __shared__ float red[GT / VG_WAVE];
-    const int vb = blockIdx.x, bs = blockIdx.y, BS = gridDim.y, vblocks = gridDim.x;
+    const int vb = blockIdx.x, bs = blockIdx.y, BS = gridDim.y, nparts = gridDim.x * (GT / VG_WAVE);
     const int lane = threadIdx.x % VG_WAVE, wave = threadIdx.x / VG_WAVE;
     const long long v = (long long)vb * GT + threadIdx.x;
     const bool ok = v < V;
+    const long long vc = ok ? v : V - 1;                               // clamped: loads stay unconditional, results are masked
     const size_t BV = (size_t)B * V;
-    float sg = 1.f, inv_var = 1.f;
-    if (ok) { sg = (float)exp(-eps[v]); inv_var = 1.f / (sg * sg); }
+    const float sg = (float)exp(-eps[vc]), inv_var = 1.f / (sg * sg);
+    float glm_v[CMAX];
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) glm_v[i] = i < C ? glm[(size_t)i * V + vc] : 0.f;
     float dsig = 0.f;
     for (int b = bs; b < B; b += BS) {
-        // pass 1: reconstruction
-        float xr = 0.f;
-        if (ok) {
-            xr = sigmoidf_(logits[(size_t)b * V + v]);
-            for (int i = 1; i <= C; ++i)
-                xr += gain[(size_t)(i - 1) * B + b] * sigmoidf_(logits[(size_t)i * BV + (size_t)b * V + v]);
+        const size_t row = (size_t)b * V + vc;
+        float sgm[CMAX + 1], gn[CMAX];
+        sgm[0] = logits[row];
+#pragma unroll
+        for (int i = 0; i < CMAX; ++i) {
+            sgm[i + 1] = i < C ? logits[(size_t)(i + 1) * BV + row] : 0.f;
+            gn[i] = i < C ? gain[(size_t)i * B + b] : 0.f;
         }
-        const float gs = g_slp[b];
-        float dxr = 0.f;
+        const float xv = x[row], gs = g_slp[b];
+#pragma unroll
+        for (int i = 0; i <= CMAX; ++i) sgm[i] = sigmoidf_(sgm[i]);
+        float xr = sgm[0];
+#pragma unroll
+        for (int i = 0; i < CMAX; ++i) xr += gn[i] * sgm[i + 1];         // (gn = 0 beyond C)
+        const float r = xv - xr;
+        const float dxr = gs * r * inv_var;                            // d slp / d x_rec = r / sigma^2
         if (ok) {
-            const float r = x[(size_t)b * V + v] - xr;
-            dxr = gs * r * inv_var;                                    // d slp / d x_rec = r / sigma^2
             dsig += gs * (r * r * inv_var / sg - 1.f / sg);            // d slp / d sigma
-            const float s0 = sigmoidf_(logits[(size_t)b * V + v]);
-            d_logits[(size_t)b * V + v] = dxr * s0 * (1.f - s0);
+            d_logits[row] = dxr * sgm[0] * (1.f - sgm[0]);
         }
-        // pass 2: per covariate
-        for (int i = 1; i <= C; ++i) {
-            float dg = 0.f;
-            if (ok) {
-                const float gn = gain[(size_t)(i - 1) * B + b];
-                const float s = sigmoidf_(logits[(size_t)i * BV + (size_t)b * V + v]);
-                const float cons = gn * s;
-                const float dd = dist[(size_t)(i - 1) * B + b];
+#pragma unroll
+        for (int i = 0; i < CMAX; ++i) {
+            if (i < C) {                                               // wave-uniform
+                const float s_ = sgm[i + 1];
+                const float dd = dist[(size_t)i * B + b];
                 float dcons = dxr;
-                if (dd > 0.f) dcons += g_dist[(size_t)(i - 1) * B + b] * (cons - glm[(size_t)(i - 1) * V + v]) / dd;
-                dg = dcons * s;
-                d_logits[(size_t)i * BV + (size_t)b * V + v] = dcons * gn * s * (1.f - s);
+                if (dd > 0.f) dcons += g_dist[(size_t)i * B + b] * (gn[i] * s_ - glm_v[i]) / dd;
+                if (ok) d_logits[(size_t)(i + 1) * BV + row] = dcons * gn[i] * s_ * (1.f - s_);
+                const float dg = wsum(ok ? dcons * s_ : 0.f);
+                if (lane == 0) part_dgain[((size_t)i * B + b) * nparts + vb * (GT / VG_WAVE) + wave] = dg;
             }
-            dg = wsum(dg);
-            __syncthreads();
-            if (lane == 0) red[wave] = dg;
-            __syncthreads();
-            if (threadIdx.x == 0)
-                part_dgain[((size_t)(i - 1) * B + b) * vblocks + vb] = (red[0] + red[1]) + (red[2] + red[3]);
         }
     }
     if (ok) part_dsig[(size_t)bs * V + v] = dsig;
@@ -181,6 +184,7 @@ __global__ void gam_bwd_fold_eps_k(const float* __restrict__ part_dsig, const do
 
 int fwd_chunks(long long V) { return (int)((V + (long long)GT * GV - 1) / ((long long)GT * GV)); }
 int bwd_vblocks(long long V) { return (int)((V + GT - 1) / GT); }
+int bwd_gain_parts(long long V) { return bwd_vblocks(V) * (GT / VG_WAVE); }
 int bwd_bs(int B) { return B < 8 ? B : 8; }
 
 // ---------------------------------------------------------------------------------- Adam
@@ -255,7 +259,7 @@ extern "C" int vg_pack_weights(const float* flat, float* packed, const int64_t* 
 extern "C" int64_t vg_gam_ws_bytes(int32_t C, int32_t B, int64_t V) {
     if (C < 0 || C > GMAXC || B <= 0 || V <= 0) return -1;
     const int64_t fwd = ((int64_t)B * fwd_chunks(V) + (int64_t)C * B * fwd_chunks(V)) * sizeof(float);
-    const int64_t bwd = ((int64_t)bwd_bs(B) * V + (int64_t)C * B * bwd_vblocks(V)) * sizeof(float);
+    const int64_t bwd = ((int64_t)bwd_bs(B) * V + (int64_t)C * B * bwd_gain_parts(V)) * sizeof(float);
     return fwd > bwd ? fwd : bwd;
 }
 
@@ -290,12 +294,17 @@ extern "C" int vg_gam_elbo_bwd(const float* logits, const float* gain, const flo
     const int vblocks = bwd_vblocks(V), BS = bwd_bs(B);
     float* part_dsig = (float*)ws;
     float* part_dgain = part_dsig + (size_t)BS * V;
-    vg_launch(gam_bwd_k, dim3(vblocks, BS), dim3(GT), 0, s, logits, gain, x, eps, glm, dist, g_slp, g_dist, (int)C, (int)B,
-              (long long)V, d_logits, part_dsig, part_dgain);
+    if (C <= 8)
+        vg_launch(gam_bwd_k<8>, dim3(vblocks, BS), dim3(GT), 0, s, logits, gain, x, eps, glm, dist, g_slp, g_dist, (int)C, (int)B,
+                  (long long)V, d_logits, part_dsig, part_dgain);
+    else if (C <= 16)
+        vg_launch(gam_bwd_k<16>, dim3(vblocks, BS), dim3(GT), 0, s, logits, gain, x, eps, glm, dist, g_slp, g_dist, (int)C, (int)B,
+                  (long long)V, d_logits, part_dsig, part_dgain);
+    else { vg_set_error("vg_gam_elbo_bwd: more than 16 covariates"); return VG_ERR_UNSUPPORTED; }
     int rc = vg_check_launch("gam_bwd");
     if (rc) return rc;
     if (C > 0) {
-        vg_launch(gam_bwd_fold_gain_k, dim3(C * B), dim3(64), 0, s, (const float*)part_dgain, (int)(C * B), vblocks, d_gain);
+        vg_launch(gam_bwd_fold_gain_k, dim3(C * B), dim3(64), 0, s, (const float*)part_dgain, (int)(C * B), bwd_gain_parts(V), d_gain);
         if ((rc = vg_check_launch("gam_bwd_fold_gain"))) return rc;
     }
     vg_launch(gam_bwd_fold_eps_k, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, s, (const float*)part_dsig, eps, BS, (long long)V, d_eps);
