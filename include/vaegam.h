@@ -193,11 +193,13 @@ int vg_gam_elbo_fwd(const float* logits, const float* gain, const float* x, cons
                     const float* glm, int32_t C, int32_t B, int64_t V, void* ws,
                     float* sum_log_prob, float* dist, float* maps_out, void* stream);
 /* backward: given g_slp[B] = dL/dsum_log_prob and g_dist[C][B] = dL/ddist, writes
- *   d_logits[G][B][V] (sigmoid backward fused), d_gain[C][B], d_eps[V] (float64). */
+ *   d_logits[G][B][V] (sigmoid backward fused), d_gain[C][B], d_eps[V] (float64) and, if d_total != NULL,
+ *   d_total[0] (+)= the sum of all of d_logits -- the bias gradient of the one-output-channel layer that produced the logits
+ *   (convt5, vae_reg_GP.py:215,264), which then needs no pass of its own over the largest gradient tensor. */
 int vg_gam_elbo_bwd(const float* logits, const float* gain, const float* x, const double* eps,
                     const float* glm, const float* dist, const float* g_slp, const float* g_dist,
                     int32_t C, int32_t B, int64_t V, void* ws,
-                    float* d_logits, float* d_gain, double* d_eps, void* stream);
+                    float* d_logits, float* d_gain, double* d_eps, float* d_total, int32_t total_accumulate, void* stream);
 
 /* Batch-norm parameter gradients from vg_bn_bwd_reduce's per-(group, channel) sums:
  *   dgamma[c] (+)= sum_g sums[g][c][1],  dbeta[c] (+)= sum_g sums[g][c][0]   (accumulate != 0 adds into the .grad buffers;

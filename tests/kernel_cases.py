@@ -114,11 +114,14 @@ def run_gam_case(dev, C, B, V, seed=0):
     tgt = [lv[0], lv[3]] + ([lv[1]] if C > 0 else [])
     gr = torch.autograd.grad((slp_r * g1).sum() + (dist_r * g2).sum(), tgt)
     dv = [logits.to(dev).clone().requires_grad_(True), gain.to(dev).clone().requires_grad_(True), x.to(dev), eps.to(dev).clone().requires_grad_(True), glm.to(dev)]
-    slp, dist = ops.GamElbo.apply(*dv)
+    lbias = torch.nn.Parameter(torch.zeros(1, device=dev))          # stands for the bias of the layer that produced the logits
+    slp, dist = ops.GamElbo.apply(*dv, lbias)
     np.testing.assert_allclose(slp.detach().cpu().numpy(), slp_r.detach().numpy(), rtol=2e-5, atol=1e-3)
     np.testing.assert_allclose(dist.detach().cpu().numpy(), dist_r.detach().numpy(), rtol=2e-5, atol=1e-5)
     dtgt = [dv[0], dv[3]] + ([dv[1]] if C > 0 else [])
     gd = torch.autograd.grad((slp * g1.to(dev)).sum() + (dist * g2.to(dev)).sum(), dtgt)
+    # explicit hand-off: the backward left sum(d_logits) in the producing layer's bias gradient
+    np.testing.assert_allclose(float(lbias.grad), float(gr[0].double().sum()), rtol=2e-4, atol=2e-4 * float(gr[0].abs().sum()) / max(gr[0].numel() ** 0.5, 1))
     for a, b_, nm in zip(gd, gr, ('d_logits', 'd_eps', 'd_gain')):
         sc = max(1.0, float(b_.abs().max()))
         np.testing.assert_allclose(a.cpu().numpy(), b_.numpy(), rtol=2e-4, atol=2e-5 * sc, err_msg=nm)

@@ -67,7 +67,7 @@ _PROTOS = {
     'vg_channel_sum': (ctypes.c_int, [vp, i32, i32, i64, vp, vp, i32, vp]),
     'vg_gam_ws_bytes': (i64, [i32, i32, i64]),
     'vg_gam_elbo_fwd': (ctypes.c_int, [vp, vp, vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, vp]),
-    'vg_gam_elbo_bwd': (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, vp]),
+    'vg_gam_elbo_bwd': (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i64, vp, vp, vp, vp, vp, i32, vp]),
     'vg_pack_weights': (ctypes.c_int, [vp, vp, vp, i32, i64, vp]),
     'vg_cholesky_f64': (ctypes.c_int, [vp, vp, i32, i32, vp]),
     'vg_conv_mm_stats_chunks': (i64, [ctypes.POINTER(MmDesc), i32]),

@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(GT)
 gam_bwd_k(const float* __restrict__ logits, const float* __restrict__ gain, const float* __restrict__ x,
           const double* __restrict__ eps, const float* __restrict__ glm, const float* __restrict__ dist,
           const float* __restrict__ g_slp, const float* __restrict__ g_dist, int C, int B, long long V,
-          float* __restrict__ d_logits, float* __restrict__ part_dsig, float* __restrict__ part_dgain) {
+          float* __restrict__ d_logits, float* __restrict__ part_dsig, float* __restrict__ part_dgain, float* __restrict__ part_tot) {
     const int vb = blockIdx.x, bs = blockIdx.y, BS = gridDim.y, nparts = gridDim.x * (GT / VG_WAVE);
     const int lane = threadIdx.x % VG_WAVE, wave = threadIdx.x / VG_WAVE;
     const long long v = (long long)vb * GT + threadIdx.x;
@@ -121,7 +121,7 @@ gam_bwd_k(const float* __restrict__ logits, const float* __restrict__ gain, cons
     float glm_v[CMAX];
 #pragma unroll
     for (int i = 0; i < CMAX; ++i) glm_v[i] = i < C ? glm[(size_t)i * V + vc] : 0.f;
-    float dsig = 0.f;
+    float dsig = 0.f, tot = 0.f;                                       // tot: sum of every d_logits element this thread writes
     for (int b = bs; b < B; b += BS) {
         const size_t row = (size_t)b * V + vc;
         float sgm[CMAX + 1], gn[CMAX];
@@ -141,7 +141,8 @@ gam_bwd_k(const float* __restrict__ logits, const float* __restrict__ gain, cons
         const float dxr = gs * r * inv_var;                            // d slp / d x_rec = r / sigma^2
         if (ok) {
             dsig += gs * (r * r * inv_var / sg - 1.f / sg);            // d slp / d sigma
-            d_logits[row] = dxr * sgm[0] * (1.f - sgm[0]);
+            const float dl = dxr * sgm[0] * (1.f - sgm[0]);
+            d_logits[row] = dl; tot += dl;
         }
 #pragma unroll
         for (int i = 0; i < CMAX; ++i) {
@@ -150,13 +151,35 @@ gam_bwd_k(const float* __restrict__ logits, const float* __restrict__ gain, cons
                 const float dd = dist[(size_t)i * B + b];
                 float dcons = dxr;
                 if (dd > 0.f) dcons += g_dist[(size_t)i * B + b] * (gn[i] * s_ - glm_v[i]) / dd;
-                if (ok) d_logits[(size_t)(i + 1) * BV + row] = dcons * gn[i] * s_ * (1.f - s_);
+                const float dl = dcons * gn[i] * s_ * (1.f - s_);
+                if (ok) { d_logits[(size_t)(i + 1) * BV + row] = dl; tot += dl; }
                 const float dg = wsum(ok ? dcons * s_ : 0.f);
                 if (lane == 0) part_dgain[((size_t)i * B + b) * nparts + vb * (GT / VG_WAVE) + wave] = dg;
             }
         }
     }
     if (ok) part_dsig[(size_t)bs * V + v] = dsig;
+    if (part_tot) {
+        tot = wsum(tot);
+        if (lane == 0) part_tot[((size_t)bs * gridDim.x + vb) * (GT / VG_WAVE) + wave] = tot;
+    }
+}
+
+// d_total (+)= sum of the per-wave totals (one block)
+__global__ void __launch_bounds__(256)
+gam_bwd_fold_total_k(const float* __restrict__ part_tot, int n, int accumulate, float* __restrict__ d_total) {
+    __shared__ double red[256 / VG_WAVE];
+    double a = 0;
+    for (int k = threadIdx.x; k < n; k += 256) a += part_tot[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+    if (threadIdx.x % VG_WAVE == 0) red[threadIdx.x / VG_WAVE] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int w = 0; w < 256 / VG_WAVE; ++w) t += red[w];
+        d_total[0] = (accumulate ? d_total[0] : 0.f) + (float)t;
+    }
 }
 
 // one wavefront per (covariate, sample) entry: lanes stride over the per-block partials, then a shuffle reduction
@@ -259,7 +282,7 @@ extern "C" int vg_pack_weights(const float* flat, float* packed, const int64_t* 
 extern "C" int64_t vg_gam_ws_bytes(int32_t C, int32_t B, int64_t V) {
     if (C < 0 || C > GMAXC || B <= 0 || V <= 0) return -1;
     const int64_t fwd = ((int64_t)B * fwd_chunks(V) + (int64_t)C * B * fwd_chunks(V)) * sizeof(float);
-    const int64_t bwd = ((int64_t)bwd_bs(B) * V + (int64_t)C * B * bwd_gain_parts(V)) * sizeof(float);
+    const int64_t bwd = ((int64_t)bwd_bs(B) * V + (int64_t)C * B * bwd_gain_parts(V) + (int64_t)bwd_bs(B) * bwd_gain_parts(V)) * sizeof(float);
     return fwd > bwd ? fwd : bwd;
 }
 
@@ -285,7 +308,7 @@ extern "C" int vg_gam_elbo_fwd(const float* logits, const float* gain, const flo
 extern "C" int vg_gam_elbo_bwd(const float* logits, const float* gain, const float* x, const double* eps,
                                const float* glm, const float* dist, const float* g_slp, const float* g_dist,
                                int32_t C, int32_t B, int64_t V, void* ws,
-                               float* d_logits, float* d_gain, double* d_eps, void* stream) {
+                               float* d_logits, float* d_gain, double* d_eps, float* d_total, int32_t total_accumulate, void* stream) {
     if (!logits || !x || !eps || !ws || !g_slp || !d_logits || !d_eps || (C > 0 && (!gain || !glm || !dist || !g_dist || !d_gain)) ||
         C < 0 || C > GMAXC || B <= 0 || V <= 0) {
         vg_set_error("vg_gam_elbo_bwd: bad arguments C=%d B=%d V=%lld", C, B, (long long)V); return VG_ERR_ARG;
@@ -294,12 +317,13 @@ extern "C" int vg_gam_elbo_bwd(const float* logits, const float* gain, const flo
     const int vblocks = bwd_vblocks(V), BS = bwd_bs(B);
     float* part_dsig = (float*)ws;
     float* part_dgain = part_dsig + (size_t)BS * V;
+    float* part_tot = d_total ? part_dgain + (size_t)C * B * bwd_gain_parts(V) : nullptr;
     if (C <= 8)
         vg_launch(gam_bwd_k<8>, dim3(vblocks, BS), dim3(GT), 0, s, logits, gain, x, eps, glm, dist, g_slp, g_dist, (int)C, (int)B,
-                  (long long)V, d_logits, part_dsig, part_dgain);
+                  (long long)V, d_logits, part_dsig, part_dgain, part_tot);
     else if (C <= 16)
         vg_launch(gam_bwd_k<16>, dim3(vblocks, BS), dim3(GT), 0, s, logits, gain, x, eps, glm, dist, g_slp, g_dist, (int)C, (int)B,
-                  (long long)V, d_logits, part_dsig, part_dgain);
+                  (long long)V, d_logits, part_dsig, part_dgain, part_tot);
     else { vg_set_error("vg_gam_elbo_bwd: more than 16 covariates"); return VG_ERR_UNSUPPORTED; }
     int rc = vg_check_launch("gam_bwd");
     if (rc) return rc;
@@ -308,7 +332,12 @@ extern "C" int vg_gam_elbo_bwd(const float* logits, const float* gain, const flo
         if ((rc = vg_check_launch("gam_bwd_fold_gain"))) return rc;
     }
     vg_launch(gam_bwd_fold_eps_k, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, s, (const float*)part_dsig, eps, BS, (long long)V, d_eps);
-    return vg_check_launch("gam_bwd_fold_eps");
+    if ((rc = vg_check_launch("gam_bwd_fold_eps"))) return rc;
+    if (d_total) {
+        vg_launch(gam_bwd_fold_total_k, dim3(1), dim3(256), 0, s, (const float*)part_tot, BS * bwd_gain_parts(V), (int)total_accumulate, d_total);
+        return vg_check_launch("gam_bwd_fold_total");
+    }
+    return VG_OK;
 }
 
 extern "C" int vg_adam_advance(double* state, double lr, double b1, double b2, void* stream) {

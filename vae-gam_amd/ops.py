@@ -665,10 +665,12 @@ def bn_conv_act(p_in, weight, bias, gamma, beta, spec, relu_in, per_group=None, 
 
 
 class GamElbo(torch.autograd.Function):
-    """(logits[G,B,V], gain[C,B], x[B,V], eps[V] f64, glm[C,V]) -> (sum_log_prob[B], dist[C,B])."""
+    """(logits[G,B,V], gain[C,B], x[B,V], eps[V] f64, glm[C,V]) -> (sum_log_prob[B], dist[C,B]).
+    `logits_bias` (optional Parameter of one element): the bias of the one-output-channel layer that produced `logits`; the backward
+    then adds sum(d_logits) into its .grad (explicit hand-off: that layer is built with bias_grad_by_consumer=True)."""
 
     @staticmethod
-    def forward(ctx, logits, gain, x, eps, glm):
+    def forward(ctx, logits, gain, x, eps, glm, logits_bias=None):
         lib = _lib.get_lib()
         G, B, V = logits.shape
         C = G - 1
@@ -680,12 +682,20 @@ class GamElbo(torch.autograd.Function):
         _call(x, 'vg_gam_elbo_fwd', _p(logits), _p(gain), _p(x), _p(eps), _p(glm), C, B, V, _p(ws), _p(slp), _p(dist),
                  None)
         ctx.save_for_backward(logits, gain, x, eps, glm, dist)
+        ctx.logits_bias = logits_bias
         return slp, dist
 
     @staticmethod
     def backward(ctx, g_slp, g_dist):
         lib = _lib.get_lib()
         logits, gain, x, eps, glm, dist = ctx.saved_tensors
+        tot = None
+        if ctx.logits_bias is not None:
+            pb = ctx.logits_bias
+            assert pb.numel() == 1
+            if pb.grad is None:
+                pb.grad = torch.zeros_like(pb)
+            tot = pb.grad
         G, B, V = logits.shape
         C = G - 1
         g_slp = _chk(g_slp.contiguous()); g_dist = _chk(g_dist.contiguous())
@@ -694,8 +704,8 @@ class GamElbo(torch.autograd.Function):
         d_gain = torch.empty_like(gain)
         d_eps = torch.empty_like(eps)
         _call(x, 'vg_gam_elbo_bwd', _p(logits), _p(gain), _p(x), _p(eps), _p(glm), _p(dist), _p(g_slp), _p(g_dist),
-                 C, B, V, _p(ws), _p(d_logits), _p(d_gain), _p(d_eps))
-        return d_logits, d_gain, None, d_eps, None
+                 C, B, V, _p(ws), _p(d_logits), _p(d_gain), _p(d_eps), _p(tot), 1)
+        return d_logits, d_gain, None, d_eps, None, None
 
 
 class LatentSample(torch.autograd.Function):

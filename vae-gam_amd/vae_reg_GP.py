@@ -307,9 +307,10 @@ class VAE(nn.Module):
         mu, w, a = self._encode_heads(x)
         return mu, w.unsqueeze(-1), torch.exp(a)
 
-    def _decode_logits(self, z, per_group):
+    def _decode_logits(self, z, per_group, last_bias_by_consumer=False):
         """z (N, z_dim), N = groups*per_group -> pre-sigmoid maps (N, V).  Batch-norm statistics are
-        kept per group of `per_group` consecutive samples (one group per one-hot variant)."""
+        kept per group of `per_group` consecutive samples (one group per one-hot variant).
+        last_bias_by_consumer: convt5's bias gradient is formed by the consumer of the logits (ops.GamElbo(..., logits_bias=))."""
         self._require_gpu(z)
         dsp = self.geom.dec
         s = self._sync()
@@ -327,7 +328,7 @@ class VAE(nn.Module):
         p, st5 = bca(p, self.convt4.weight, self.convt4.bias, None, None, dsp[3], True, per_group, False, s, self._packed,
                      next_bn=per_group, bias_grad_by_consumer=True)
         p = bca(p, self.convt5.weight, self.convt5.bias, self.bnt5.weight, self.bnt5.bias, dsp[4], True, per_group, False, s, self._packed,
-                pre_stats=st5, producer_bias=self.convt4.bias)
+                pre_stats=st5, producer_bias=self.convt4.bias, bias_grad_by_consumer=last_bias_by_consumer)
         return p.reshape(p.shape[0], self.img_dim)
 
     def decode(self, z):
@@ -469,7 +470,7 @@ class VAE(nn.Module):
             mu, w, a = heads
             zcat, kl_z, d = ops.LatentSample.apply(mu, w, a, eps_w, eps_d, G)
         z, u = zcat[:B, :L], w.unsqueeze(-1)
-        logits = self._decode_logits(zcat, B).view(G, B, self.img_dim)
+        logits = self._decode_logits(zcat, B, last_bias_by_consumer=True).view(G, B, self.img_dim)
         task_var, gp_kl_loss, beta_mean, beta_cov, post = gains
         if gains_stream is not None:
             torch.cuda.current_stream(dev).wait_stream(gains_stream)
@@ -478,7 +479,7 @@ class VAE(nn.Module):
         if joint_gains:
             task_var = task_var[:, lo:lo + B].contiguous()                                  # full-batch gains, this rank's columns
         xf = x.reshape(B, self.img_dim)
-        slp, dist = ops.GamElbo.apply(logits, task_var, xf, self.epsilon.view(-1), self._glm())
+        slp, dist = ops.GamElbo.apply(logits, task_var, xf, self.epsilon.view(-1), self._glm(), self.convt5.bias)
         # glm_reg = Bg * sum(dist) (:388-389, cdist's factor = global batch); elbo = sum(-kl_z + slp) / Bg (:406-408);
         # loss = -elbo + gp_kl_scale * gp_kl + glm_reg_scale * glm_reg (:410) -- one launch.  Replicated terms are
         # divided by the world size: the gradient all-reduce SUMS the per-rank losses.
