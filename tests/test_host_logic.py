@@ -203,6 +203,20 @@ def test_nifti1_reader_and_writer_against_spec_fixtures(tmp_path):
     assert open(p2, 'rb').read() == open(os.path.join(GOLDEN, 'nifti1_3x4x5_f32_be.nii'), 'rb').read()
 
 
+def test_device_prefetcher_is_a_pass_through_on_cpu(small_ds, tmp_path):
+    """DataClass_GP.DevicePrefetcher on a CPU device hands out the wrapped loader's batches unchanged; setup_data_loaders without
+    prefetch_device returns plain DataLoaders (the reference's)."""
+    csv, _ = synthetic.write_csvs(small_ds, str(tmp_path))
+    loaders = DataClass_GP.setup_data_loaders(batch_size=4, train_csv=csv, test_csv=csv)
+    assert type(loaders['test']).__name__ == 'DataLoader'
+    pf = DataClass_GP.DevicePrefetcher(loaders['UnShuffled_train'], 'cpu')
+    assert len(pf) == len(loaders['UnShuffled_train']) and pf.dataset is loaders['UnShuffled_train'].dataset
+    for a, b in zip(pf, loaders['UnShuffled_train']):
+        assert sorted(a) == sorted(b)
+        for k in a:
+            assert torch.equal(a[k], b[k])
+
+
 def test_mk_avg_maps_from_device_sums(tmp_path):
     """Subject means and the grand mean (mean of subject means, build_model_recons.py:86-99) from the sums reconstruct() leaves."""
     import pandas as pd

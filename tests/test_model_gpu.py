@@ -484,6 +484,30 @@ def test_cli_two_ranks_train_on_disjoint_halves_of_the_global_batches(tmp_path):
     assert os.path.isdir(_cli_files(str(tmp_path / 'run_w2'), 2)[1])     # rank 0 ran the export
 
 
+def test_device_prefetcher_yields_the_loaders_batches_on_the_device(tmp_path):
+    """minibatches of the NIfTI/CSV data path staged in pinned host memory and copied one batch ahead on a side stream
+    are the same minibatches, on the device, in the same order; a train epoch through the prefetcher equals one through the loader."""
+    from vae_gam_amd import DataClass_GP, synthetic
+    ds = synthetic.make_dataset(num_subjects=2, vols_per_subject=5, num_covariates=8, seed=3)
+    csv, _ = synthetic.write_csvs(ds, str(tmp_path))
+    plain = DataClass_GP.setup_data_loaders(batch_size=4, train_csv=csv, test_csv=csv)
+    pre = DataClass_GP.setup_data_loaders(batch_size=4, train_csv=csv, test_csv=csv, prefetch_device='cuda')
+    assert isinstance(pre['test'], DataClass_GP.DevicePrefetcher) and len(pre['test']) == len(plain['test'])
+    n = 0
+    for a, b in zip(pre['UnShuffled_train'], plain['UnShuffled_train']):
+        for k in b:
+            assert a[k].is_cuda and torch.equal(a[k].cpu(), b[k]), k
+        n += 1
+    assert n == 3
+    losses = []
+    for ld in (plain['UnShuffled_train'], pre['UnShuffled_train']):
+        torch.manual_seed(1)
+        m = VAE(num_covariates=8, glm_maps=ds['glm'], xu_ranges=ds['xu_ranges'], device_name='cuda', save_dir=str(tmp_path))
+        torch.manual_seed(7)
+        losses.append(m.train_epoch(ld))
+    assert losses[0] == losses[1]
+
+
 def test_bench_emits_the_contract_line():
     """bench.py (the driver's entry point): ONE JSON line on stdout with the metric, the roofline object of the dominant
     kernel (HIP events on the launch stream) and the CPU baseline timed in the same run."""

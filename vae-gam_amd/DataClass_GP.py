@@ -100,13 +100,59 @@ class ToTensor(object):
                 'vol_num': torch.tensor(sample['vol_num'], dtype=torch.float64)}
 
 
-def setup_data_loaders(batch_size=32, shuffle=(True, False, False), train_csv='', test_csv=''):
-    """{'Shuffled_train', 'UnShuffled_train', 'test'} loaders (DataClass_GP.py:73-89)."""
+def setup_data_loaders(batch_size=32, shuffle=(True, False, False), train_csv='', test_csv='', prefetch_device=None):
+    """{'Shuffled_train', 'UnShuffled_train', 'test'} loaders (DataClass_GP.py:73-89).
+    prefetch_device (extension): a CUDA device -> the loaders collate into pinned host memory and are wrapped in DevicePrefetcher."""
     train_dataset = FMRIDataset(csv_file=train_csv, transform=ToTensor())
     test_dataset = FMRIDataset(csv_file=test_csv, transform=ToTensor())
-    mk = lambda ds, sh: DataLoader(ds, batch_size=batch_size, shuffle=sh, num_workers=0)
-    return {'Shuffled_train': mk(train_dataset, shuffle[0]), 'UnShuffled_train': mk(train_dataset, shuffle[1]),
-            'test': mk(test_dataset, shuffle[2])}
+    pin = prefetch_device is not None and torch.device(prefetch_device).type == 'cuda'
+    mk = lambda ds, sh: DataLoader(ds, batch_size=batch_size, shuffle=sh, num_workers=0, pin_memory=pin)
+    out = {'Shuffled_train': mk(train_dataset, shuffle[0]), 'UnShuffled_train': mk(train_dataset, shuffle[1]),
+           'test': mk(test_dataset, shuffle[2])}
+    return {k: DevicePrefetcher(v, prefetch_device) for k, v in out.items()} if pin else out
+
+
+class DevicePrefetcher:
+    """A DataLoader iterated ONE BATCH AHEAD (real-data input path): while the train step of minibatch k runs, minibatch
+    k+1 is collated (into pinned host memory if the loader pins) and copied to the device on a separate HIP stream; the consumer's
+    stream waits on the copy's event only when it takes the batch.  The reference copies every tensor of every minibatch with a
+    blocking .to(device) inside the step loop (vae_reg_GP.py:420-423).  Yields the same sample dictionaries, tensors on the device.
+    On a CPU device it is a pass-through."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+        self.dataset = loader.dataset                           # len(loader.dataset) as the train loop uses it
+        self.batch_sampler = getattr(loader, 'batch_sampler', None)
+        self.collate_fn = getattr(loader, 'collate_fn', None)
+        self._stream = torch.cuda.Stream(self.device) if self.device.type == 'cuda' else None
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, sample):
+        if sample is None:
+            return None
+        with torch.cuda.stream(self._stream):
+            out = {k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in sample.items()}
+            ev = torch.cuda.Event()
+            ev.record(self._stream)
+        return out, ev
+
+    def __iter__(self):
+        if self._stream is None:
+            yield from self.loader
+            return
+        it = iter(self.loader)
+        nxt = self._stage(next(it, None))
+        while nxt is not None:
+            cur, ev = nxt
+            nxt = self._stage(next(it, None))                    # the next copy is queued before this batch is handed out
+            here = torch.cuda.current_stream(self.device)
+            here.wait_event(ev)
+            for v in cur.values():
+                if torch.is_tensor(v):
+                    v.record_stream(here)                        # allocated on the copy stream, used on the consumer's
+            yield cur
 
 
 class DeviceResidentData:

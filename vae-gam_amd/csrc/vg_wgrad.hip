@@ -725,6 +725,9 @@ int launch_plane(const vg_wgrad_desc* d, const float* a, const float* b, const f
 #else
 #define VG_WG_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+#ifndef VG_WG_MINB
+#define VG_WG_MINB 1
+#endif
 template <int V> struct vg_int { static constexpr int value = V; };
 template <int N, int I = 0, typename F>
 __host__ __device__ inline void vg_static_for(F&& f) { if constexpr (I < N) { f(vg_int<I>{}); vg_static_for<N, I + 1>(f); } }
@@ -746,7 +749,7 @@ struct WgradRowsParams {
 };
 
 template <int CA, int TC, int KD, int KH, int KW, int S, bool PAD, bool PA, int UG, bool RES, bool GRP = false>
-__global__ void __launch_bounds__(256, (CA * TC >= 32 ? 2 : 1))         // 32 accumulator tiles: keep two waves per SIMD (<= 256 registers)
+__global__ void __launch_bounds__(256, (CA * TC >= 32 ? 2 : CA * TC >= 16 ? VG_WG_MINB : 1))         // 32 accumulator tiles: keep two waves per SIMD (<= 256 registers)
 wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ in_scale,
              const float* __restrict__ in_shift, float* __restrict__ ws, WgradRowsParams p) {
     VG_DYN_SMEM(float, lds);
@@ -991,6 +994,9 @@ int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const fl
     static const long cap_env = getenv("VG_WGRAD_LDS") ? atol(getenv("VG_WGRAD_LDS")) : 0;
     // LDS per block: measured sweep (tools/layer_bench.py, VG_WGRAD_LDS): 56 KB is best or equal for every layer of the net
     // (convt4 212 -> 187 us, convt2 104 -> 92, convt5 130 -> 119 vs 24-48 KB); 64 KB leaves one block per CU too few
+    // (measured and NOT adopted: compiling the 16-24-tile instances for three waves per SIMD (-DVG_WG_MINB=3, 166 registers, no spills) with
+    //  48 KB tiles is 6 % faster per layer in tools/layer_bench.py -- convt4 799 -> 753 us, convt3 345 -> 326 -- but not in the step, where these
+    //  launches share the GPU with the gain block's backward on the second stream: 8.17-8.22 vs 8.21-8.24 ms)
     const size_t cap = cap_env > 0 ? (size_t)cap_env : (size_t)56 * 1024;
     (void)narrow;
     const size_t red_fl = (size_t)NT * 4 * VG_WAVE;

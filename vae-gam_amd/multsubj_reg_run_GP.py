@@ -62,8 +62,10 @@ def main(argv=None):
         raise SystemExit('--batch-size %d (the GLOBAL minibatch) must be a multiple of the %d ranks' % (args.batch_size, dp.world_size))
     # the reference's loaders (whole data set, global minibatch): what the export pipeline iterates; under data parallelism the
     # train / test loops get re-built loaders that hand each rank its slice of every global minibatch
+    # (single process on a GPU: minibatches are staged in pinned memory and copied one batch ahead on a side stream)
     full_loaders = data.setup_data_loaders(batch_size=args.batch_size if dp is None else args.batch_size // dp.world_size,
-                                           train_csv=args.train_csv, test_csv=args.test_csv)
+                                           train_csv=args.train_csv, test_csv=args.test_csv,
+                                           prefetch_device='cuda' if (dp is None and torch.cuda.is_available()) else None)
     loaders_dict = full_loaders if dp is None else dp.shard_loaders(full_loaders, args.batch_size, args.seed)
     model = vae_reg.VAE(num_inducing_pts=args.num_inducing_pts, gp_kl_scale=args.gp_kl_scale,
                         glm_reg_scale=args.glm_reg_scale, glm_maps=args.glm_maps, save_dir=args.save_dir,

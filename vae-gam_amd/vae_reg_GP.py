@@ -189,7 +189,7 @@ class VAE(nn.Module):
         self._hrf_cache = {}
         self._gain_const_cache = {}
         self._gain_streams = {}
-        self.overlap_gains = True      # run the gain algebra on a second stream beside the conv stacks
+        self.overlap_gains = os.environ.get('VG_OVERLAP_GAINS', '1') != '0'      # run the gain algebra on a second stream beside the conv stacks
         self._glm_f32 = None
         self.use_hip_graph = False     # capture the train step into a hipGraph (bench / long runs)
         self.recon_sums = None         # per-subject map sums left by reconstruct() for build_model_recons.mk_avg_maps
