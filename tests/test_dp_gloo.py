@@ -35,7 +35,7 @@ def _single_process_reference():
     return float(loss), g32['g'].clone(), g32['p'].clone(), model.epsilon.detach().clone()
 
 
-def _rank_main(rank, world, port, out_dir, dp_gain='global'):
+def _rank_main(rank, world, port, out_dir, dp_gain='global', C=C):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     torch.set_num_threads(2)
     from vae_gam_amd import dp as dpmod
@@ -86,7 +86,8 @@ def test_local_gain_mode_draws_each_ranks_slice_from_its_own_covariance(tmp_path
     (its own B x B gain covariance, its columns of the noise tape) -- no all-gather, cost independent of the number of ranks --
     while batch-norm statistics, the loss normalisation and the gradient sum stay global: replicas remain identical."""
     port = _free_port()
-    mp.spawn(_rank_main, args=(2, port, str(tmp_path), 'local'), nprocs=2, join=True)
+    C = 8                                                        # the full covariate set (HRF on task, 6 GP regressors, sex) under data parallelism
+    mp.spawn(_rank_main, args=(2, port, str(tmp_path), 'local', C), nprocs=2, join=True)
     outs = [torch.load(os.path.join(tmp_path, 'rank%d.pt' % r)) for r in range(2)]
     assert torch.equal(outs[0]['p'], outs[1]['p']) and torch.equal(outs[0]['g'], outs[1]['g'])
     T.load_emu_library()
