@@ -247,7 +247,7 @@ struct CorrPlaneParams {
 };
 constexpr int PLANE_SLACK = 8;  // floats in front of the LDS buffer: a window may start at iw = -pad
 
-template <int COT, int KD, int KH, int KW, int S, int TDt, int THt, int TW, int COC>
+template <int COT, int KD, int KH, int KW, int S, int TDt, int THt, int TW, int COC, bool NOPRO = false>
 __global__ void __launch_bounds__(256, (TDt * THt * TW > 16 ? 2 : 3))
 corr3d_plane_k(const float* __restrict__ x, const float* __restrict__ wpk, const float* __restrict__ bias,
                const float* __restrict__ in_scale, const float* __restrict__ in_shift,
@@ -296,7 +296,14 @@ corr3d_plane_k(const float* __restrict__ x, const float* __restrict__ wpk, const
             // VEC_MASK multiplies instead of selecting: clamp to a plane that WAS staged (0 * real data is 0, 0 * LDS garbage may be NaN)
             const int lp = VEC_MASK ? clampi(id, pl_lo, max(pl_hi - 1, pl_lo)) - ip0 : clampi(id - ip0, 0, p.LD - 1);
             roff[dz][hy] = lp * plane + clampi(ih, 0, d.IH - 1) * d.IW + iw_t;
+            // NOPRO (no ReLU / affine on the input: the data-gradient launches): a row outside the tensor reads the zeroed tail of the
+            // channel slot instead, so an element costs ONE v_and (column mask) instead of max + fma + and
+            if (NOPRO && !rok[dz][hy]) roff[dz][hy] = p.ch_floats - 32;
         }
+    if (NOPRO) {
+        for (int c = 0; c < p.CCH * p.nbuf; ++c)
+            for (int i = tid; i < 64; i += blockDim.x) lds[c * p.ch_floats + p.ch_floats - 64 + i] = 0.f;     // never touched by the DMA
+    }
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
         const int iw = iw_t + i;
@@ -359,7 +366,10 @@ corr3d_plane_k(const float* __restrict__ x, const float* __restrict__ wpk, const
                     for (int hy = 0; hy < RH; ++hy) {
                         const float* row = tl + roff[dz][hy];
                         float seg[RW];
-                        if constexpr (VEC_MASK) {
+                        if constexpr (NOPRO) {
+#pragma unroll
+                            for (int i = 0; i < RW; ++i) seg[i] = vg_and(row[i], cokm[i]);
+                        } else if constexpr (VEC_MASK) {
                             const float scr = sc * rokf[dz][hy], shr = sh * rokf[dz][hy];      // (clamped rows hold real, finite data)
 #pragma unroll
                             for (int i = 0; i < RW; ++i) seg[i] = vg_and(fmaf(vg_max(row[i], lo), scr, shr), cokm[i]);
@@ -481,6 +491,13 @@ int launch_corr_plane(const vg_conv_desc* d, const float* x, const float* wpk, c
     if (d->CO % COT) { vg_set_error("corr3d: CO=%d not a multiple of %d", d->CO, COT); return VG_ERR_UNSUPPORTED; }
     const int threads = vg_cdiv(p.TWG * p.TH * p.TD, VG_WAVE) * VG_WAVE;
     dim3 grid(p.tilesD, d->N, d->CO / COT);
+    if constexpr (KD == 5) {                                     // (the instances built with vector masks; the one-channel one always has a prologue)
+        if (in_scale == nullptr && !d->relu_in) {
+            vg_launch(corr3d_plane_k<COT, KD, KH, KW, S, TDt, THt, TW, COC, true>, grid, dim3(threads), shmem, s,
+                      x, wpk, bias, in_scale, in_shift, mask_src, y, p);
+            return vg_check_launch("corr3d_plane");
+        }
+    }
     vg_launch(corr3d_plane_k<COT, KD, KH, KW, S, TDt, THt, TW, COC>, grid, dim3(threads), shmem, s,
               x, wpk, bias, in_scale, in_shift, mask_src, y, p);
     return vg_check_launch("corr3d_plane");
