@@ -275,7 +275,8 @@ def main():
                        'detail': 'BASELINE.json configs[%s]: synthetic checker control (Large3 glyph, block design), GP regressors on the '
                                  'continuous covariates, HRF on task, GLM regulariser on; gain / GP algebra on device in fp64'
                                  % ('2' if (B, C) == (64, 8) else '1' if (B, C) == (32, 3) else '-'),
-                       'global_batch': B * world, 'covariates': C, 'parallelism': 'dp%d' % world},
+                       'global_batch': B * world, 'covariates': C, 'parallelism': 'dp%d' % world,
+                       **({'dp': 'batch-norm statistics and loss normalisation over the global minibatch (all-reduced), one gradient all-reduce, gains drawn per rank from its own slice (dp_gain=%s)' % model.dp_gain} if world > 1 else {})},
             'roofline': roofline,
             'step_roofline': {'hbm_frac': round(value / world * ALG_BYTES_PER_VOL.get(C, 0) / (HBM_PEAK_GBS * 1e9), 4),
                               'fp32_frac': round(value / world * ALG_GFLOP_PER_VOL.get(C, 0) / (FP32_PEAK_TF * 1e3), 4),
