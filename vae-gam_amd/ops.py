@@ -56,11 +56,12 @@ def _call(t, fn, *args):
 
 # Parameter-gradient kernels (weight gradient, bias sum) of a layer depend on dy but nothing downstream depends
 # on them until the optimiser: they run on a second HIP stream beside the data-gradient chain (which is what the
-# next layer's backward waits for).  Measured on MI355X at batch 32 (hipGraph replay): 7.75 ms/step with the side
-# stream vs 7.29 ms without -- the persistent weight-gradient blocks hold the LDS of every CU, so the chains do not
-# overlap and the extra stream joins only add boundaries.  Left off; kept because it may pay at smaller batches.
+# next layer's backward waits for).  Round 1 measured a LOSS (7.75 vs 7.29 ms/step at batch 32: the persistent
+# weight-gradient blocks of that time held the LDS of every CU, so the chains did not overlap and the extra joins only
+# added boundaries).  With round 2's kernels (2-3 weight-gradient blocks per CU at 56 KB, matrix-core data gradients)
+# the two chains do overlap: 8.10 -> 7.85 ms/step at batch 64 / 8 covariates, 3.20 -> 3.03 at batch 32 / 3.  On.
 import os as _os
-SIDE_STREAM = bool(int(_os.environ.get('VG_SIDE_STREAM', '0')))
+SIDE_STREAM = bool(int(_os.environ.get('VG_SIDE_STREAM', '1')))
 FUSE_LAST_BN_BWD = bool(int(_os.environ.get('VG_FUSE_LAST_BN_BWD', '1')))     # bnt5 backward + convt5 data gradient in two fused passes
 WGRAD_BN_SUMS = bool(int(_os.environ.get('VG_WGRAD_BN_SUMS', '1')))          # bnt5's backward reductions from convt5's grouped weight gradient (no reduce pass)
 FC_SIDE_STREAM = bool(int(_os.environ.get('VG_FC_SIDE_STREAM', '0')))     # fully connected dW/db on the second stream: measured 4.41 vs 4.28 ms/step (worse), off
