@@ -184,7 +184,14 @@ def main():
     if graphed:
         # events cannot be recorded inside a replayed graph: time the same launches, same stream, eagerly,
         # right after the timed region (the kernels and their arguments are identical)
+        # The step overlaps two launch chains (parameter gradients and the gain block on a second stream): inside it a kernel's
+        # elapsed time includes the time it shares the GPU.  The per-kernel pass therefore runs the same launches one after the other
+        # (second stream off), so that a kernel's duration -- and the roofline fraction derived from it -- is the kernel's own;
+        # `ms_per_step` / `value` above are the overlapped step as shipped.  profiles/<tag>_kernel_stats_serial.csv is rocprofv3's
+        # view of the same serial launches (VG_SIDE_STREAM=0 VG_OVERLAP_GAINS=0), <tag>_kernel_stats.csv of the step as shipped.
         model.use_hip_graph = False
+        ops.SIDE_STREAM = False
+        model.overlap_gains = False
         ops.PROFILE = {}
         run_steps(max(3, min(a.steps, 10)), a.warmup + a.steps)
         torch.cuda.synchronize()
@@ -223,6 +230,7 @@ def main():
                     'traffic': (traffic_tab.get(key) or {}).get('hbm_bytes_per_launch') if traffic_ok else None,
                     'alg_bytes_per_launch': ab,
                     'avg_launch_us': round(per * 1e3, 2), 'launches': n,
+                    'timed': 'launches serialised (second stream off) in the per-kernel pass' if graphed else 'inside the timed region (overlapped chains)',
                     'share_of_kernel_time': round(tot / max(sum(r[0] for r in rows), 1e-9), 3)}
         break
     if a.kernel_table and rank == 0:

@@ -26,21 +26,23 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 C = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 out_dir = os.path.join(ROOT, 'profiles')
 
-# ---- kernel stats
-f = one('gpurun_out/%s_stats/**/*kernel_stats.csv' % tag)
-if f:
-    rows = list(csv.DictReader(open(f)))
-    tot = sum(float(r['TotalDurationNs']) for r in rows)
-    with open(os.path.join(out_dir, '%s_kernel_stats.csv' % tag), 'w') as o:
-        o.write('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline   (MI355X, BASELINE configs[2]: batch %d, %d covariates;\n' % (B, C))
-        o.write('# 10 timed steps replayed from the hipGraph + warm-up/capture + one eager pass for the per-kernel HIP events)\n')
-        o.write('Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n')
-        for r in rows[:90]:
-            o.write('"%s",%s,%s,%s,%.2f,%s,%s\n' % (short(r['Name'])[:140], r['Calls'], r['TotalDurationNs'], r['AverageNs'],
-                                                    100 * float(r['TotalDurationNs']) / tot, r['MinNs'], r['MaxNs']))
-    ours = sum(float(r['TotalDurationNs']) for r in rows if re.search(r'_k<|_k\(|_k$|adam|gather_f32|pack_weights|gain_|chol', short(r['Name'])))
-    print('kernel time: %.1f ms total, %.1f %% in this library\'s kernels, %d distinct kernels, %d launches' %
-          (tot / 1e6, 100 * ours / tot, len(rows), sum(int(r['Calls']) for r in rows)))
+# ---- kernel stats: the step as shipped (two overlapping launch chains) and the same launches serialised (a kernel's own duration)
+for sub, outname, how in (('stats_serial', '%s_kernel_stats_serial.csv', 'VG_SIDE_STREAM=0 VG_OVERLAP_GAINS=0 (every launch on one stream: a kernel\'s own duration) '),
+                          ('stats', '%s_kernel_stats.csv', '')):
+  f = one('gpurun_out/%s_%s/**/*kernel_stats.csv' % (tag, sub))
+  if f:
+      rows = list(csv.DictReader(open(f)))
+      tot = sum(float(r['TotalDurationNs']) for r in rows)
+      with open(os.path.join(out_dir, outname % tag), 'w') as o:
+          o.write('# %srocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline   (MI355X, BASELINE configs[2]: batch %d, %d covariates;\n' % (how, B, C))
+          o.write('# 10 timed steps replayed from the hipGraph + warm-up/capture + one eager pass for the per-kernel HIP events)\n')
+          o.write('Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n')
+          for r in rows[:90]:
+              o.write('"%s",%s,%s,%s,%.2f,%s,%s\n' % (short(r['Name'])[:140], r['Calls'], r['TotalDurationNs'], r['AverageNs'],
+                                                      100 * float(r['TotalDurationNs']) / tot, r['MinNs'], r['MaxNs']))
+      ours = sum(float(r['TotalDurationNs']) for r in rows if re.search(r'_k<|_k\(|_k$|adam|gather_f32|pack_weights|gain_|chol', short(r['Name'])))
+      print('kernel time: %.1f ms total, %.1f %% in this library\'s kernels, %d distinct kernels, %d launches' %
+            (tot / 1e6, 100 * ours / tot, len(rows), sum(int(r['Calls']) for r in rows)))
 
 # ---- per-dispatch traffic, grouped by (kernel, grid size) so that layers sharing a kernel instance stay apart
 traffic = collections.defaultdict(dict)
