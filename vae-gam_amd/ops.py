@@ -623,6 +623,9 @@ class BnConvAct(torch.autograd.Function):
         return dp, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
 
 
+_MM_SKIP = set(filter(None, _os.environ.get('VG_MM_SKIP', '').split(',')))
+
+
 def mm_wins(plan):
     """Where vg_conv_mm is the faster (or an equally fast) engine -- MI355X, tools/layer_bench.py at batch 64 / 8 covariates, us,
     register-tiled kernel -> matrix-core kernel:
@@ -634,6 +637,8 @@ def mm_wins(plan):
     Kept on the register-tiled kernels: stride-2 correlations (convt4's data gradient 574 vs 714: one input channel fills the
     LDS budget, a unit is 57 MFMAs per wave between barriers; conv2 / conv4 forward)."""
     if plan is None:
+        return False
+    if _MM_SKIP and 'k%d' % plan.ks[0] in _MM_SKIP and (plan.PDT + plan.PD - 1) // plan.PD > 1:     # tuning knob: VG_MM_SKIP=k7,k9 -> those go register-tiled
         return False
     if USE_MM >= 2 or (plan.PDT + plan.PD - 1) // plan.PD == 1:
         return True
