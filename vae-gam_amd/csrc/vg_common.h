@@ -67,12 +67,17 @@ struct VgPrologue {
 #ifdef VG_EMU
 static inline void vg_dma4(const float* gsrc, float* lds_row_base) { lds_row_base[emu_tid % 64] = *gsrc; }
 static inline void vg_dma_wait() {}
+// lanes are host fibers here: the wave-wide completion a real vmcnt(0) gives (a lane may then read what its neighbours copied) is a
+// wave barrier; call it from wave-uniform code only
+static inline void vg_dma_wait_wave() { emu_wait(g_emu_block->waves[emu_tid / 64].bar); }
 #else
 __device__ __forceinline__ void vg_dma4(const float* gsrc, float* lds_row_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_row_base, 4, 0, 0);
 }
 __device__ __forceinline__ void vg_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// same instruction; the name says that the caller then reads LDS bytes OTHER lanes of its wave copied (a wave waits as a whole)
+__device__ __forceinline__ void vg_dma_wait_wave() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
 
 // Wave-cooperative copy of n contiguous floats -> LDS: the full 64-float DMA instructions carry no per-lane predicate

@@ -22,6 +22,15 @@
 #include <stdint.h>
 #include "../../include/vaegam.h"
 
+#ifdef VG_STAMP
+// Diagnostic build only (tools/stamp_bench.py): per-wave cycle sums of the phases of a unit, read back through vg_stamp_read.
+__device__ unsigned long long vg_stamp_out[1024 * 16 * 8];
+#define VG_STAMP_T(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define VG_STAMP_ADD(i) do { unsigned long long t_; VG_STAMP_T(t_); st_sum[i] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define VG_STAMP_ADD(i) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int MM_T = 512;                  // 8 wavefronts: two per SIMD.  (Measured alternative: 4-wave workgroups, 2-3 per CU, single-buffered
@@ -39,6 +48,8 @@ struct MmParams {
     int tau_off, in_off;                   // LDS float offsets
     int has_pro;
 };
+
+struct alignas(16) mm_f4 { float v[4]; };   // one ds_read_b128 / ds_write_b128
 
 template <int V> struct mm_int { static constexpr int value = V; };
 // f(mm_int<n>) for the run-time n in [1, MAXN]
@@ -60,8 +71,17 @@ __device__ __forceinline__ void mm_static_for(F&& f) {
 // every LDS read of a channel is issued ahead of the matrix instructions that consume it (a run-time loop pays two dependent LDS
 // latencies per step).  Classes (NQ = 4: the output parities of a stride-2 transposed conv) are processed one after the other on
 // the same staged input, each stored as soon as it is finished: its stores drain behind the next class's matrix work.
-template <int NQ, int TPC, int K0, int K1, int K2, int K3>
-__global__ void __launch_bounds__(MM_T)
+//
+// Round 3 (in-kernel stamps, tools/diag/stamp_bench.py): inside the matrix phase the MFMA pipe is 75-87 % busy, but it idles through the
+// phases every wave of a block enters together -- input wait / prologue / barrier / epilogue stores were 32 % (convt3 fwd) to 60 %
+// (convt4 fwd, convt3's data gradient) of a wave's cycles.  So: (i) OCC = waves per SIMD the register budget is held to (4 = 128
+// VGPRs: TWO blocks per CU whose phases interleave); (ii) DB = 0 stages the input single-buffered (half the LDS: what lets two
+// blocks fit; the co-resident block covers the exposed copy); (iii) the epilogue works from per-tile output offsets and validity
+// bits set up once per block, stores through a uniform base + 32-bit lane offset, and -- data gradients -- fetches the ReLU mask
+// of a sample BEFORE that sample's last matrix phase instead of between its stores (that wait was 48 % of convt3's data gradient);
+// (iv) a wave copies AND post-processes whole channel spans (16-byte LDS accesses), statistics are flushed per group run.
+template <int NQ, int TPC, int K0, int K1, int K2, int K3, bool DB, int OCC, bool MASKED>
+__global__ void __launch_bounds__(MM_T, OCC)
 conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const int* __restrict__ tau, const int* __restrict__ dlt,
           const float* __restrict__ bias, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
           const float* __restrict__ mask_src, float* __restrict__ y, double* __restrict__ stats_part, int stats_pg, int stats_relu,
@@ -81,7 +101,7 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
 
     for (int i = tid; i < p.aimg_floats; i += MM_T) Al[i] = a_img[i];
     if (!STATIC_K) for (int i = tid; i < p.kstot * 64; i += MM_T) Tl[i] = tau[(i >> 6) * 4 + ((i & 63) >> 4)];
-    for (int i = tid; i < 2 * d.cc * MM_ZPAD; i += MM_T) In[(i / MM_ZPAD) * p.CHP + (i % MM_ZPAD)] = 0.f;  // the zero pads of both buffers (never written again)
+    for (int i = tid; i < (DB ? 2 : 1) * d.cc * MM_ZPAD; i += MM_T) In[(i / MM_ZPAD) * p.CHP + (i % MM_ZPAD)] = 0.f;  // the zero pads (never written again)
 
     // ---- geometry of this block (the same for every sample it visits)
     const int pd0 = b * d.PD;
@@ -92,11 +112,18 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
     const int pl_lo = max(dlo, 0), pl_hi = min(dlo + d.LD, d.ID);
     const int nfl = max(pl_hi - pl_lo, 0) * IHW;                         // floats to copy per channel
     const int dst0 = (pl_lo - dlo) * IHW;
+    const size_t vol = (size_t)IHW * d.ID, ovol = (size_t)OHW * d.OD;
+    // rows 4*kk .. 4*kk+3 of a tile: replica and first channel are lane constants
+    const int rho_l = (CO == 8) ? (kk >> 1) : 0;
+    const int co_l = (CO == 8) ? ((kk & 1) * 4) : kk * 4;
     // Per accumulator tile and k-step: WHERE this lane's B operand sits inside a channel slot -- the element (pd*sdi + dd, ph*shi + dh,
     // pw*swi + dw) of the staged planes, or, where that element does not exist (zero padding, tile overhang, lanes past the last
     // position), the slot's zero pad.  Float offsets from the slot base; with compile-time step counts they live in registers
     // (pt), so a matrix instruction costs one address add + one ds_read_b32 and no select.
-    int pcoord[TPC];
+    // Per tile: ob = offset of the lane's first output element of class 0 inside the sample (channel co_l, replica rho_l); bit
+    // q*TPC + i of vbits = "tile i of class q writes an element that exists".
+    int ob[TPC];
+    unsigned vbits = 0;
     int pt[TPC][STATIC_K ? KSUM : 1];
     int posBase[TPC]; unsigned vm[NQ][TPC];                              // run-time step counts only
 #pragma unroll
@@ -106,7 +133,14 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
         const int pfc = pv ? pf : 0;
         const int pdl = pfc / (d.PH * d.PW), r2 = pfc - pdl * (d.PH * d.PW);
         const int ph = r2 / d.PW, pw = r2 - ph * d.PW;
-        pcoord[i] = pv ? ((pdl << 20) | (ph << 10) | pw) : -1;
+        const int obd = (pd0 + pdl) * d.sdo, obh = ph * d.sho, obw = pw * d.swo + rho_l;
+        ob[i] = obd * OHW + obh * d.OW + obw + co_l * (int)ovol;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int od = obd + d.od0[q], oh = obh + d.oh0[q], ow = obw + d.ow0[q];
+            const bool ok = pv && od >= 0 && od < d.OD && oh >= 0 && oh < d.OH && ow >= 0 && ow < d.OW;
+            vbits |= (ok ? 1u : 0u) << (q * TPC + i);
+        }
         const int pb = (pdl * d.sdi - d.d0) * IHW + ph * d.shi * d.IW + pw * d.swi;
         posBase[i] = pb;
         if constexpr (STATIC_K) {
@@ -132,16 +166,13 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
         }
     }
     const float lo = d.relu_in ? 0.f : -__builtin_inff();
-    const size_t vol = (size_t)IHW * d.ID, ovol = (size_t)OHW * d.OD;
     const int nchunks = (CI + d.cc - 1) / d.cc;
     const int nsamp = (d.N - split + p.nsplit - 1) / p.nsplit;          // samples this block visits: split, split + nsplit, ...
     const int units = nsamp * nchunks;
 
     vg_f32x4 acc[TPC];
     float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
-    // rows 4*kk .. 4*kk+3 of a tile: replica and first channel are lane constants
-    const int rho_l = (CO == 8) ? (kk >> 1) : 0;
-    const int co_l = (CO == 8) ? ((kk & 1) * 4) : kk * 4;
+    float mreg[MASKED ? TPC : 1][4];                                     // ReLU mask source of the sample in flight (data gradients)
     float bias_l[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias_l[r] = bias ? bias[co_l + r] : 0.f;
@@ -153,31 +184,45 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
 #pragma unroll
         for (int i = 0; i < TPC; ++i) { acc[i].v[0] = 0.f; acc[i].v[1] = 0.f; acc[i].v[2] = 0.f; acc[i].v[3] = 0.f; }
     };
-    // store class q of sample n from the accumulators: lane owns position jl of each tile, rows 4*kk .. 4*kk+3
-    auto store_class = [&](int n, int q) __attribute__((always_inline)) {
-        float* yn = y + (size_t)n * CO * ovol;
-        const float* mn = mask_src ? mask_src + (size_t)n * CO * ovol : nullptr;
-        const int od0 = d.od0[q], oh0 = d.oh0[q], ow0 = d.ow0[q] + rho_l;
+    // fetch the mask source of sample n's outputs (class 0) into registers; consumed by store_class
+    auto load_mask = [&](int n) __attribute__((always_inline)) {
+        const char* mn = reinterpret_cast<const char*>(mask_src + (size_t)n * CO * ovol);
 #pragma unroll
         for (int i = 0; i < TPC; ++i) {
-            if (i >= nact || pcoord[i] < 0) continue;
-            const int pdl = pcoord[i] >> 20, ph = (pcoord[i] >> 10) & 1023, pw = pcoord[i] & 1023;
-            const int od = (pd0 + pdl) * d.sdo + od0, oh = ph * d.sho + oh0, ow = pw * d.swo + ow0;
-            if (od < 0 || od >= d.OD || oh < 0 || oh >= d.OH || ow < 0 || ow >= d.OW) continue;
-            const int sp = od * OHW + oh * d.OW + ow;
+            const bool okt = i < nact && ((vbits >> i) & 1u);
+            const unsigned off = okt ? 4u * (unsigned)(ob[i] + d.od0[0] * OHW + d.oh0[0] * d.OW + d.ow0[0]) : 0u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                mreg[i][r] = okt ? *reinterpret_cast<const float*>(mn + (size_t)r * ovol * 4 + off) : 0.f;
+        }
+    };
+    // store class q of sample n from the accumulators: lane owns position jl of each tile, rows 4*kk .. 4*kk+3
+    auto store_class = [&](int n, int q) __attribute__((always_inline)) {
+        char* yn = reinterpret_cast<char*>(y + (size_t)n * CO * ovol);
+        const char* mn = reinterpret_cast<const char*>(mask_src + (size_t)n * CO * ovol);
+        const int cq = d.od0[q] * OHW + d.oh0[q] * d.OW + d.ow0[q];       // wave-uniform
+#pragma unroll
+        for (int i = 0; i < TPC; ++i) {
+            if (i >= nact || !((vbits >> (q * TPC + i)) & 1u)) continue;
+            const unsigned off = 4u * (unsigned)(ob[i] + cq);             // bytes inside the sample: uniform base + 32-bit lane offset
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int idx = sp + (co_l + r) * (int)ovol;              // < 2^31: one sample of one layer
                 float v = acc[i].v[r] + bias_l[r];
-                if (mn) v = (mn[idx] > 0.f) ? v : 0.f;
-                yn[idx] = v;
-                const float h = stats_relu ? vg_max(v, 0.f) : v;
-                st_s[r] += h; st_q[r] = fmaf(h, h, st_q[r]);
+                if constexpr (MASKED) {
+                    if constexpr (NQ == 1) v = (mreg[i][r] > 0.f) ? v : 0.f;                       // fetched before the matrix phase
+                    else v = (*reinterpret_cast<const float*>(mn + (size_t)r * ovol * 4 + off) > 0.f) ? v : 0.f;
+                }
+                *reinterpret_cast<float*>(yn + (size_t)r * ovol * 4 + off) = v;
+                if (stats_part) {
+                    const float h = stats_relu ? vg_max(v, 0.f) : v;
+                    st_s[r] += h; st_q[r] = fmaf(h, h, st_q[r]);
+                }
             }
         }
     };
     auto flush_stats = [&](int n) __attribute__((always_inline)) {
-        // per wavefront and sample: [sum, sum of squares] of relu?(y) per channel, laid out for vg_bn_stats_from_parts
+        // per wavefront and run of samples of one group: [sum, sum of squares] of relu?(y) per channel, in the slot of the run's last
+        // sample (the other slots of the run stay zero), laid out for vg_bn_stats_from_parts
         const int g = n / stats_pg;
         const size_t chunks = (size_t)stats_pg * p.bps * MM_W;
         const size_t chunkid = ((size_t)(n % stats_pg) * p.bps + b) * MM_W + wave;
@@ -195,39 +240,70 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
         }
     };
 
-    // input planes of unit u (sample, channel chunk) -> buffer u & 1: one contiguous span per channel, flat LDS-DMA
+    // Input planes of unit u (sample, channel chunk): one contiguous span per channel, flat LDS-DMA.  The span of a channel is cut into
+    // `parts` pieces of whole 16-byte groups and every (channel, piece) belongs to ONE wave, which copies it and -- after its own
+    // vmcnt(0) -- applies the producer's ReLU / batch-norm affine to it in place: no barrier between copy and prologue.
+    const int parts = (d.cc >= MM_W) ? 1 : MM_W / d.cc;
+    const int head = dst0 & 3;                                           // the span starts `head` floats past a 16-byte boundary of its slot
+    const int n4 = (head + nfl + 3) >> 2;                                // 16-byte groups that cover it
+    const int n4p = (n4 + parts - 1) / parts;
     auto stage = [&](int u) __attribute__((always_inline)) {
         const int n = split + (u / nchunks) * p.nsplit, c0 = (u % nchunks) * d.cc;
         const int cc = min(d.cc, CI - c0);
-        float* buf = In + (u & 1) * p.buf_floats;
+        float* buf = In + (DB ? (u & 1) : 0) * p.buf_floats;
         const float* src0 = x + ((size_t)n * CI + c0) * vol + (size_t)pl_lo * IHW;
-        for (int c = 0; c < cc; ++c) {
-            const float* src = src0 + (size_t)c * vol;
-            float* dst = buf + c * p.CHP + MM_ZPAD + dst0;
-            for (int o = wave * VG_WAVE; o < nfl; o += MM_T)
-                if (o + lane < nfl) vg_dma4(src + o + lane, dst + o);
+        for (int it = wave; it < cc * parts; it += MM_W) {
+            const int c = it / parts, part = it - c * parts;
+            const int g0 = part * n4p, g1 = min(g0 + n4p, n4);
+            const int f0 = max(g0 * 4 - head, 0), f1 = min(g1 * 4 - head, nfl);    // floats [f0, f1) of the span
+            if (f1 > f0) vg_dma_span(src0 + (size_t)c * vol + f0 + lane, buf + c * p.CHP + MM_ZPAD + dst0 + f0, f1 - f0, lane);
+        }
+    };
+    auto prologue = [&](int u) __attribute__((always_inline)) {
+        const int n = split + (u / nchunks) * p.nsplit, c0 = (u % nchunks) * d.cc;
+        const int cc = min(d.cc, CI - c0);
+        float* buf = In + (DB ? (u & 1) : 0) * p.buf_floats;
+        const int g_aff = (in_scale != nullptr) ? n / d.per_group : 0;
+        for (int it = wave; it < cc * parts; it += MM_W) {
+            const int c = it / parts, part = it - c * parts;
+            float sc = 1.f, sh = 0.f;
+            if (in_scale != nullptr) { sc = in_scale[g_aff * CI + c0 + c]; sh = in_shift[g_aff * CI + c0 + c]; }
+            mm_f4* v4 = reinterpret_cast<mm_f4*>(buf + c * p.CHP + MM_ZPAD + dst0 - head);   // 16-byte aligned: slot bases and dst0 - head are
+            const int g1 = min((part + 1) * n4p, n4);
+            // the first / last group may hold up to 3 floats outside the span: they lie past the zero pad and no operand offset points at them
+            for (int g = part * n4p + lane; g < g1; g += VG_WAVE) {
+                mm_f4 t = v4[g];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t.v[e] = fmaf(vg_max(t.v[e], lo), sc, sh);
+                v4[g] = t;
+            }
         }
     };
     __syncthreads();
-    if (units > 0) stage(0);
+#ifdef VG_STAMP
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+    VG_STAMP_T(st_last);
+#endif
+    if (DB && units > 0) stage(0);
+    int g_run = -1, n_run = 0;                                           // statistics: group / last sample of the running partial sums
     for (int u = 0; u < units; ++u) {
         const int n = split + (u / nchunks) * p.nsplit, chunk = u % nchunks, c0 = chunk * d.cc;
         const int cc = min(d.cc, CI - c0);
-        float* cur = In + (u & 1) * p.buf_floats;
-        vg_dma_wait();                                                   // this thread's share of unit u has landed
-        if (p.has_pro) {
-            // ReLU / batch-norm affine once per staged element, by the thread that copied it (same loop shape as the copy)
-            const int g_aff = (in_scale != nullptr) ? n / d.per_group : 0;
-            for (int c = 0; c < cc; ++c) {
-                float sc = 1.f, sh = 0.f;
-                if (in_scale != nullptr) { sc = in_scale[g_aff * CI + c0 + c]; sh = in_shift[g_aff * CI + c0 + c]; }
-                float* dst = cur + c * p.CHP + MM_ZPAD + dst0;
-                for (int o = wave * VG_WAVE; o < nfl; o += MM_T)
-                    if (o + lane < nfl) dst[o + lane] = fmaf(vg_max(dst[o + lane], lo), sc, sh);
-            }
+        float* cur = In + (DB ? (u & 1) : 0) * p.buf_floats;
+        VG_STAMP_ADD(7);
+        if (!DB) {
+            if (u > 0) __syncthreads();                                  // every wave has read the last operand of unit u-1
+            stage(u);
         }
+        vg_dma_wait_wave();                                              // this wave's share of unit u has landed
+        VG_STAMP_ADD(0);
+        if (p.has_pro) prologue(u);
+        VG_STAMP_ADD(1);
         __syncthreads();                                                 // unit u complete in LDS; every wave is past unit u-1
-        if (u + 1 < units) stage(u + 1);                                 // into the buffer unit u-1 used: lands behind this unit's matrix work
+        VG_STAMP_ADD(2);
+        if (DB && u + 1 < units) stage(u + 1);                           // into the buffer unit u-1 used: lands behind this unit's matrix work
+        if constexpr (NQ == 1 && MASKED) { if (chunk == nchunks - 1) load_mask(n); }   // lands behind the matrix phase
+        VG_STAMP_ADD(3);
         // ---- matrix work.  The body is instantiated per number of tiles THIS wave owns (wave-uniform): no per-tile branches inside.
         auto class_work = [&](auto qc, auto ntc) __attribute__((always_inline)) {
             constexpr int q = decltype(qc)::value;
@@ -290,26 +366,42 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
                 }
             }
         };
+        const int g_now = stats_part ? n / stats_pg : 0;
+        if (stats_part && chunk == 0 && g_run >= 0 && g_now != g_run) flush_stats(n_run);   // the run of g_run's samples has ended
         if constexpr (NQ == 1) {
             if (chunk == 0) zero_acc();
             if (nact > 0) mm_dispatch<TPC>(nact, [&](auto ntc) __attribute__((always_inline)) { class_work(mm_int<0>{}, ntc); });
-            if (chunk == nchunks - 1) {
-                store_class(n, 0);
-                if (stats_part) flush_stats(n);
-            }
+            VG_STAMP_ADD(4);
+            if (chunk == nchunks - 1) store_class(n, 0);
+            VG_STAMP_ADD(5);
         } else {
             // all channels are resident (the host plans one chunk per sample for multi-class layers)
             mm_static_for<NQ>([&](auto qc) __attribute__((always_inline)) {
                 zero_acc();
+                VG_STAMP_ADD(5);
                 if (nact > 0) mm_dispatch<TPC>(nact, [&](auto ntc) __attribute__((always_inline)) { class_work(qc, ntc); });
+                VG_STAMP_ADD(4);
                 store_class(n, decltype(qc)::value);
             });
-            if (stats_part) flush_stats(n);
+            VG_STAMP_ADD(5);
         }
+        g_run = g_now; n_run = n;
     }
+    if (stats_part && g_run >= 0) flush_stats(n_run);
+    VG_STAMP_ADD(6);
+#ifdef VG_STAMP
+    if (lane == 0 && blockIdx.x < 1024)
+        for (int i = 0; i < 8; ++i) vg_stamp_out[(blockIdx.x * 16 + wave) * 8 + i] = st_sum[i];
+#endif
 }
 
 }  // namespace
+
+#ifdef VG_STAMP
+extern "C" int vg_stamp_read(unsigned long long* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(vg_stamp_out), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 static int mm_plan_params(const vg_mm_desc* d, MmParams* p, size_t* shmem, const char* who) {
     if (!d || d->N <= 0 || d->CI <= 0 || (d->CO != 8 && d->CO != 16) || d->nq < 1 || d->nq > MM_MAXQ || d->PD <= 0 || d->PDT <= 0 ||
@@ -334,7 +426,7 @@ static int mm_plan_params(const vg_mm_desc* d, MmParams* p, size_t* shmem, const
     p->a_res = 1;
     p->tau_off = ((p->aimg_floats + 63) / 64) * 64;
     p->in_off = p->tau_off + p->kstot * 64;
-    const size_t total = (size_t)p->in_off + 2 * (size_t)p->buf_floats + 64;
+    const size_t total = (size_t)p->in_off + (d->dbuf ? 2 : 1) * (size_t)p->buf_floats + 64;
     *shmem = total * sizeof(float);
     if (*shmem > 160 * 1024) { vg_set_error("%s: plan needs %zu bytes of LDS", who, *shmem); return VG_ERR_UNSUPPORTED; }
     if (d->PD * d->PH * d->PW > d->tpc * MM_W * 16) { vg_set_error("%s: %d positions per block exceed tpc=%d", who, d->PD * d->PH * d->PW, d->tpc); return VG_ERR_ARG; }
@@ -357,23 +449,35 @@ extern "C" int vg_conv_mm(const vg_mm_desc* d, const float* x, const float* a_im
     if (stats_part && (stats_per_group <= 0 || d->N % stats_per_group)) { vg_set_error("vg_conv_mm: bad statistics arguments"); return VG_ERR_ARG; }
     p.has_pro = (d->relu_in || in_scale) ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(p.bps * p.nsplit), block(MM_T);
-#define MM_LAUNCH(NQ, TPC, K0, K1, K2, K3) \
-    vg_launch(conv_mm_k<NQ, TPC, K0, K1, K2, K3>, grid, block, shmem, s, x, a_img, (const int*)tau, (const int*)dlt, bias, in_scale, in_shift, \
-              mask_src, y, stats_part, (int)(stats_part ? stats_per_group : 1), (int)stats_relu, p)
+    // persistent grid = the blocks that are resident at once (occupancy query of the chosen instance x 256 CUs), dealt over the
+    // bps position slabs of a sample: every further block of a slab takes every nsplit-th sample
+    auto launch = [&](auto kernel) {
+        const int bpc = vg_blocks_per_cu((const void*)kernel, MM_T, shmem);
+        int ns = (256 * bpc) / p.bps; if (ns < 1) ns = 1; if (ns > d->N) ns = d->N;
+        p.nsplit = ns;
+        vg_launch(kernel, dim3(p.bps * p.nsplit), dim3(MM_T), shmem, s, x, a_img, (const int*)tau, (const int*)dlt, bias, in_scale, in_shift,
+                  mask_src, y, stats_part, (int)(stats_part ? stats_per_group : 1), (int)stats_relu, p);
+    };
+    const bool db = d->dbuf != 0, mk = mask_src != nullptr;
+    // OCC: 4 waves per SIMD (128 registers, two blocks per CU) where the per-(tile, step) operand offsets leave room for it
+#define MM_LAUNCH(NQ, TPC, K0, K1, K2, K3) { \
+        constexpr int OCC_ = (TPC * (K0 + K1 + K2 + K3) + 10 * TPC <= 96 && K0 > 0) ? 4 : 2; \
+        if (db) { if (mk) launch(conv_mm_k<NQ, TPC, K0, K1, K2, K3, true, OCC_, true>); else launch(conv_mm_k<NQ, TPC, K0, K1, K2, K3, true, OCC_, false>); } \
+        else    { if (mk) launch(conv_mm_k<NQ, TPC, K0, K1, K2, K3, false, OCC_, true>); else launch(conv_mm_k<NQ, TPC, K0, K1, K2, K3, false, OCC_, false>); } }
 #define MM_TPC(NQ, K0, K1, K2, K3) \
-    { if (d->tpc <= 3) MM_LAUNCH(NQ, 3, K0, K1, K2, K3); else if (d->tpc <= 6) MM_LAUNCH(NQ, 6, K0, K1, K2, K3); else MM_LAUNCH(NQ, 8, K0, K1, K2, K3); }
+    { if (d->tpc <= 3) MM_LAUNCH(NQ, 3, K0, K1, K2, K3) else if (d->tpc <= 4) MM_LAUNCH(NQ, 4, K0, K1, K2, K3) else if (d->tpc <= 5) MM_LAUNCH(NQ, 5, K0, K1, K2, K3) \
+      else if (d->tpc <= 6) MM_LAUNCH(NQ, 6, K0, K1, K2, K3) else MM_LAUNCH(NQ, 8, K0, K1, K2, K3) }
     const int* k = d->ks;
     if (d->nq == 1 && d->tpc <= 8) {
         if (k[0] == 7) MM_TPC(1, 7, 0, 0, 0)
         else if (k[0] == 9) MM_TPC(1, 9, 0, 0, 0)
         else if (k[0] == 12) MM_TPC(1, 12, 0, 0, 0)
-        else if (k[0] == 19 && d->tpc <= 3) MM_LAUNCH(1, 3, 19, 0, 0, 0);
+        else if (k[0] == 19 && d->tpc <= 3) MM_LAUNCH(1, 3, 19, 0, 0, 0)
         else MM_TPC(1, 0, 0, 0, 0)
     } else if (d->nq == 4 && d->tpc <= 4) {
-        if (k[0] == 3 && k[1] == 2 && k[2] == 2 && k[3] == 1) MM_LAUNCH(4, 4, 3, 2, 2, 1);
-        else if (k[0] == 2 && k[1] == 1 && k[2] == 1 && k[3] == 1) MM_LAUNCH(4, 4, 2, 1, 1, 1);
-        else MM_LAUNCH(4, 4, 0, 0, 0, 0);
+        if (k[0] == 3 && k[1] == 2 && k[2] == 2 && k[3] == 1) MM_LAUNCH(4, 4, 3, 2, 2, 1)
+        else if (k[0] == 2 && k[1] == 1 && k[2] == 1 && k[3] == 1) MM_LAUNCH(4, 4, 2, 1, 1, 1)
+        else MM_LAUNCH(4, 4, 0, 0, 0, 0)
     } else { vg_set_error("vg_conv_mm: no kernel instance for %d classes x %d tiles per wave", d->nq, d->tpc); return VG_ERR_UNSUPPORTED; }
 #undef MM_TPC
 #undef MM_LAUNCH

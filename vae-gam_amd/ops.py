@@ -643,8 +643,8 @@ def mm_wins(plan):
     if USE_MM >= 2 or (plan.PDT + plan.PD - 1) // plan.PD == 1:
         return True
     if plan.mode == 'tconv':
-        return list(plan.ks) == [3, 2, 2, 1]
-    return plan.sdi == 1 and plan.ks[0] in (7, 9)
+        return list(plan.ks) in ([3, 2, 2, 1], [2, 1, 1, 1])
+    return plan.ks[0] in (7, 9)
 
 
 def _mm_for(packed, weight, spec, direction, read_size, write_size):
@@ -1017,6 +1017,14 @@ def adam_step_(p, g, m, v, b1, b2, eps, step_scalars):
 # --------------------------------------------------------------------------- matrix-core convolution plans (vg_conv_mm)
 USE_MM = int(_os.environ.get('VG_CONV_MM', '1'))            # 0: off; 1: where it measured faster (mm_wins); 2: wherever a plan exists
 _MM_LDS_BUDGET = 150 * 1024
+_MM_LDS_HALF = 80 * 1024                                    # two blocks per CU
+# (mode, stride, CI, CO, kernel, read size, write size) -> (PD, cc, dbuf): tools/diag/mm_sweep.py at batch 64, 8 covariates
+_MM_TUNED = {
+    ('corr', 1, 16, 16, (3, 3, 3), (6, 8, 5), (8, 10, 7)): (4, 16, 0),          # convt1 forward 66.7 us (score's choice: 78)
+    ('corr', 1, 16, 16, (3, 3, 3), (8, 10, 7), (6, 8, 5)): (3, 16, 0),          # convt1 data gradient 37.8
+    ('corr', 2, 16, 16, (3, 3, 3), (16, 21, 14), (8, 10, 7)): (2, 8, 0),        # convt2 data gradient 83.2
+    ('corr', 1, 16, 8, (3, 3, 3), (17, 21, 14), (19, 23, 16)): (1, 8, 0),       # conv3 data gradient 61.6
+}
 _MM_WAVES = 8
 
 
@@ -1038,7 +1046,7 @@ class MmPlan:
     def desc(self, N, relu_in, per_group):
         d = _lib.MmDesc()
         for k in ('CI', 'CO', 'ID', 'IH', 'IW', 'OD', 'OH', 'OW', 'nq', 'PDT', 'PH', 'PW', 'PD', 'sdi', 'shi', 'swi', 'd0', 'LD', 'cc', 'sdo', 'sho',
-                  'swo', 'tpc', 'slack'):
+                  'swo', 'tpc', 'slack', 'dbuf'):
             setattr(d, k, int(getattr(self, k)))
         d.N, d.relu_in, d.per_group = int(N), int(bool(relu_in)), int(per_group)
         for q in range(4):
@@ -1090,12 +1098,12 @@ def _mm_problem(spec: ConvSpec, direction: str, in_size):
 _MM_PLANS = {}
 
 
-def mm_plan(spec: ConvSpec, direction: str, in_size, out_size=None) -> Optional[MmPlan]:
+def mm_plan(spec: ConvSpec, direction: str, in_size, out_size=None, force=None) -> Optional[MmPlan]:
     """Plan for vg_conv_mm, or None when the launch is not covered (1-channel ends, 16-channel stride-2 transposed convs, shapes
     that do not fit LDS): the caller then uses the register-tiled kernels.  `in_size`: spatial size of the tensor the launch READS
     (the layer input for 'fwd', dy for 'bwd'); `out_size`: spatial size it writes (needed for 'bwd')."""
     import numpy as np
-    key = (spec, direction, tuple(in_size), None if out_size is None else tuple(out_size))
+    key = (spec, direction, tuple(in_size), None if out_size is None else tuple(out_size), force)
     if key in _MM_PLANS:
         return _MM_PLANS[key]
     mode, S, pad, CI, CO, K, osz, widx = _mm_problem(spec, direction, tuple(in_size))
@@ -1103,12 +1111,13 @@ def mm_plan(spec: ConvSpec, direction: str, in_size, out_size=None) -> Optional[
         osz = tuple(out_size)
     plan = None
     if CO in (8, 16) and CI >= 8 and not (mode == 'tconv' and CO != 8):
-        plan = _mm_build(mode, S, pad, CI, CO, K, tuple(in_size), tuple(osz), widx)
+        plan = _mm_build(mode, S, pad, CI, CO, K, tuple(in_size), tuple(osz), widx, force)
     _MM_PLANS[key] = plan
     return plan
 
 
-def _mm_build(mode, S, pad, CI, CO, K, isz, osz, widx):
+def _mm_build(mode, S, pad, CI, CO, K, isz, osz, widx, force=None):
+    """force = (PD, cc): tuning sweeps (tools/diag) pin the tile instead of taking the scored choice."""
     import numpy as np
     KD, KH, KW = K
     ID, IH, IW = isz
@@ -1189,7 +1198,12 @@ def _mm_build(mode, S, pad, CI, CO, K, isz, osz, widx):
         r0 += ks[q]
     aidx = np.concatenate(aidx)
     tpc_max = (8 if max(ks) <= 12 else 3) if nq == 1 else 4        # registers: one operand offset per (tile, k-step)
-    best = None
+    # Tile choice.  Measured (tools/diag/mm_sweep.py, MI355X): what pays is TWO co-resident blocks per CU -- their input waits,
+    # prologues, barriers and epilogues interleave with each other's matrix phases -- i.e. at most half the LDS (single-buffered input
+    # where double does not fit) and at most 3 tiles per wave (the 128-register instances); then full accumulator columns, a small halo
+    # and large channel chunks.  _MM_TUNED pins the bench geometries where the sweep found a better tile than this score.
+    tuned = _MM_TUNED.get((mode, S, CI, CO, tuple(K), tuple(isz), tuple(osz))) if force is None else None
+    cands = []
     for PD in range(min(PDT, 16), 0, -1):
         npos = PD * PH * PW
         tpc = (npos + _MM_WAVES * 16 - 1) // (_MM_WAVES * 16)
@@ -1197,24 +1211,29 @@ def _mm_build(mode, S, pad, CI, CO, K, isz, osz, widx):
             continue
         LD = ld_of(PD)
         CHP = 64 + ((LD * IHW + 63) // 64) * 64
+        bps = (PDT + PD - 1) // PD
         for cc in ([CI] if nq > 1 else [c for c in range(CI, 0, -1) if CI % c == 0]):
-            lds = aidx.size * 4 + rows * 64 * 4 + 2 * cc * CHP * 4 + 512
-            if lds > _MM_LDS_BUDGET:
-                continue
-            bps = (PDT + PD - 1) // PD
-            util = npos / float(tpc * _MM_WAVES * 16) * (PDT / float(bps * PD))          # filled accumulator columns
-            halo = (PD * sdi) / float(LD)                                                  # useful share of the staged planes
-            fill = min(1.0, (bps * max(1, 256 // bps)) / 256.0)
-            score = util * (0.5 + 0.5 * halo) * fill * (1.0 if cc == CI else 0.95)
-            if best is None or score > best[0] + 1e-9:
-                best = (score, PD, LD, cc, tpc)
-            break                                                                          # smaller chunks of the same PD only score lower
-    if best is None:
+            for dbuf in (1, 0):
+                if (force or tuned) and (PD, cc, dbuf) != tuple(force or tuned):
+                    continue
+                lds = (((aidx.size + 63) // 64) * 64 + rows * 64 + (1 + dbuf) * cc * CHP + 64) * 4
+                if lds > _MM_LDS_BUDGET:
+                    continue
+                two = lds <= _MM_LDS_HALF and (tpc <= 3 or nq > 1)
+                util = npos / float(tpc * _MM_WAVES * 16) * (PDT / float(bps * PD))          # filled accumulator columns
+                halo = (PD * sdi) / float(LD)                                                  # useful share of the staged planes
+                fill = min(1.0, (bps * max(1, 256 // bps)) / 256.0)
+                score = util * (0.5 + 0.5 * halo) * fill * (0.9 + 0.1 * cc / float(CI)) * (1.0 if two else 0.6) * (1.0 if (dbuf or two) else 0.9)
+                cands.append((score, PD, LD, cc, tpc, dbuf))
+    if not cands:
         return None
-    _, PD, LD, cc, tpc = best
-    tpc = {1: (3 if tpc <= 3 else 6 if tpc <= 6 else 8), 4: 4}[nq]
+    if _os.environ.get('VG_MM_DEBUG'):
+        for c in sorted(cands, reverse=True)[:6]:
+            print('mm_plan cand', mode, CI, CO, isz, c)
+    _, PD, LD, cc, tpc, dbuf = max(cands, key=lambda c: (round(c[0], 9), c[3], -c[5]))
+    tpc = {1: (3 if tpc <= 3 else tpc if tpc <= 6 else 8), 4: 4}[nq]
     return MmPlan(CI=CI, CO=CO, ID=ID, IH=IH, IW=IW, OD=OD, OH=OH, OW=OW, nq=nq, ks=ks, PDT=PDT, PH=PH, PW=PW, PD=PD, sdi=sdi, shi=shi,
-                  swi=swi, d0=d0, LD=LD, cc=cc, sdo=sdo, sho=sho, swo=swo, od0=od0, oh0=oh0, ow0=ow0, tpc=tpc, slack=slack,
+                  swi=swi, d0=d0, LD=LD, cc=cc, sdo=sdo, sho=sho, swo=swo, od0=od0, oh0=oh0, ow0=ow0, tpc=tpc, slack=slack, dbuf=dbuf,
                   tau=tau.reshape(-1), dlt=dlt.reshape(-1), aidx=aidx, mode=mode)
 
 
