@@ -47,7 +47,7 @@ for item in which:
     sc = torch.ones((N // B) * sp.ci, device=dev); sh = torch.zeros((N // B) * sp.ci, device=dev)
     if direction == 'fwd':
         mm = ops._mm_for(None, w, sp, 'fwd', sizes[i], None)
-        fn = lambda: ops.conv_mm(x, mm[0], mm[1], b, True, sc, sh, B, None, B if name in ('convt2', 'convt4') else None)
+        fn = lambda: ops.conv_mm(x, mm[0], mm[1], b, True, sc, sh, B, None, (B if name in ('convt2', 'convt4') and not os.environ.get('VG_NOSTATS') else None))
     else:
         dy = torch.randn((N, sp.co) + sizes[i + 1], device=dev)
         mm = ops._mm_for(None, w, sp, 'bwd', sizes[i + 1], sizes[i])

@@ -93,6 +93,50 @@ __device__ __forceinline__ void vg_dma_span(const float* src_lane, float* dst, i
 }
 #endif
 
+// 16 bytes per lane (global_load_lds_dwordx4): source and LDS destination 16-byte aligned, n a multiple of 4.  src_lane = source + 4*lane.
+#ifdef VG_EMU
+static inline void vg_dma_span16(const float* src_lane, float* dst, int n, int lane) {
+    for (int o = 0; o + 4 * lane < n; o += 256) for (int e = 0; e < 4; ++e) dst[o + 4 * lane + e] = src_lane[o + e];
+}
+#else
+__device__ __forceinline__ void vg_dma16(const float* gsrc, float* lds_row_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_row_base, 16, 0, 0);
+}
+__device__ __forceinline__ void vg_dma_span16(const float* src_lane, float* dst, int n, int lane) {
+    for (; n >= 256; n -= 256, src_lane += 256, dst += 256) vg_dma16(src_lane, dst);
+    if (4 * lane < n) vg_dma16(src_lane, dst);
+}
+#endif
+
+// Wait until at most n (wave-uniform, a multiple of 4 up to 32) of this wave's vector-memory operations are outstanding: they retire in
+// issue order, so everything issued BEFORE the last n -- e.g. an LDS-DMA copy issued ahead of n stores -- has completed, while the stores
+// keep draining.  n outside the table waits for everything.
+#ifdef VG_EMU
+static inline void vg_wait_vm(int) { emu_wait(g_emu_block->waves[emu_tid / 64].bar); }
+static inline bool vg_any(bool p) {
+    EmuWave& w = g_emu_block->waves[emu_tid / 64]; const int lane = emu_tid % 64;
+    w.fbuf[lane] = p ? 1.f : 0.f; emu_wait(w.bar);
+    bool r = false; for (int l = 0; l < w.lanes; ++l) r = r || (w.fbuf[l] != 0.f);
+    emu_wait(w.bar); return r;
+}
+#else
+__device__ __forceinline__ void vg_wait_vm(int n) {
+    switch (n) {
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+        case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+__device__ __forceinline__ bool vg_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+#endif
+
 // Read-only kernel arguments that must stay on the SCALAR load path (weights indexed by wave-uniform values): loads through
 // the constant address space are invariant by definition, so the compiler keeps them s_load even in kernels that also
 // store to LDS/global (where its no-clobber analysis otherwise gives up and turns them into per-lane VMEM loads + VGPRs).

@@ -47,6 +47,7 @@ struct MmParams {
     int CHP, buf_floats;                   // channel pitch, floats of the input buffer
     int tau_off, in_off;                   // LDS float offsets
     int has_pro;
+    int x4;                                // input spans and tensor base 16-byte aligned: 16-byte LDS-DMA
 };
 
 struct alignas(16) mm_f4 { float v[4]; };   // one ds_read_b128 / ds_write_b128
@@ -93,6 +94,7 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
     float* In = lds + p.in_off;
     const int tid = threadIdx.x, lane = tid % VG_WAVE, wave = vg_wave_id();
     const int kk = lane >> 4, jl = lane & 15;
+    // (an XCD-aware order -- the slabs of one sample on one XCD, so that they share the halo planes in its L2 -- measured neutral to 15 % slower)
     const int b = blockIdx.x % p.bps, split = blockIdx.x / p.bps;
     const int IHW = d.IH * d.IW, OHW = d.OH * d.OW;
     const int CI = d.CI, CO = d.CO;
@@ -180,6 +182,16 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
 #pragma unroll
     for (int i = 0; i < TPC; ++i) nact += (i * MM_W + wave < ntiles) ? 1 : 0;
 
+    // stores a wave issues for class q (4 per tile with a lane that writes): what a counted vmcnt lets fly past the next input wait
+    int nst[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        int c4 = 0;
+#pragma unroll
+        for (int i = 0; i < TPC; ++i) c4 += (vg_any(((vbits >> (q * TPC + i)) & 1u) != 0) && i < nact) ? 4 : 0;
+        nst[q] = c4;
+    }
+
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < TPC; ++i) { acc[i].v[0] = 0.f; acc[i].v[1] = 0.f; acc[i].v[2] = 0.f; acc[i].v[3] = 0.f; }
@@ -212,7 +224,19 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
                     if constexpr (NQ == 1) v = (mreg[i][r] > 0.f) ? v : 0.f;                       // fetched before the matrix phase
                     else v = (*reinterpret_cast<const float*>(mn + (size_t)r * ovol * 4 + off) > 0.f) ? v : 0.f;
                 }
+#if defined(VG_ABLATE_STORE) && VG_ABLATE_STORE == 1
+                if (v == 1.2345e-30f) *reinterpret_cast<float*>(yn + (size_t)r * ovol * 4 + off) = v;        // diagnostic: (almost) no store
+#elif defined(VG_ABLATE_STORE) && VG_ABLATE_STORE == 2
+                *reinterpret_cast<float*>(yn + (size_t)r * ovol * 4 + (((off >> 8) << 8) + 4u * lane)) = v;    // diagnostic: one aligned 256-byte run per instruction
+#elif defined(VG_ABLATE_STORE) && VG_ABLATE_STORE == 4
+                if (r == 0 || v == 1.2345e-30f) *reinterpret_cast<float*>(yn + (size_t)r * ovol * 4 + off) = v;            // diagnostic: a quarter of the stores
+#elif defined(VG_ABLATE_STORE) && VG_ABLATE_STORE == 5
+                *reinterpret_cast<float*>(yn + off) = v;                                                         // diagnostic: all four stores to the first one's address
+#elif defined(VG_ABLATE_STORE) && VG_ABLATE_STORE == 3
+                __builtin_nontemporal_store(v, reinterpret_cast<float*>(yn + (size_t)r * ovol * 4 + off));          // diagnostic: nt stores
+#else
                 *reinterpret_cast<float*>(yn + (size_t)r * ovol * 4 + off) = v;
+#endif
                 if (stats_part) {
                     const float h = stats_relu ? vg_max(v, 0.f) : v;
                     st_s[r] += h; st_q[r] = fmaf(h, h, st_q[r]);
@@ -256,7 +280,10 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
             const int c = it / parts, part = it - c * parts;
             const int g0 = part * n4p, g1 = min(g0 + n4p, n4);
             const int f0 = max(g0 * 4 - head, 0), f1 = min(g1 * 4 - head, nfl);    // floats [f0, f1) of the span
-            if (f1 > f0) vg_dma_span(src0 + (size_t)c * vol + f0 + lane, buf + c * p.CHP + MM_ZPAD + dst0 + f0, f1 - f0, lane);
+            if (f1 > f0) {
+                if (p.x4) vg_dma_span16(src0 + (size_t)c * vol + f0 + 4 * lane, buf + c * p.CHP + MM_ZPAD + dst0 + f0, f1 - f0, lane);
+                else vg_dma_span(src0 + (size_t)c * vol + f0 + lane, buf + c * p.CHP + MM_ZPAD + dst0 + f0, f1 - f0, lane);
+            }
         }
     };
     auto prologue = [&](int u) __attribute__((always_inline)) {
@@ -271,31 +298,45 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
             mm_f4* v4 = reinterpret_cast<mm_f4*>(buf + c * p.CHP + MM_ZPAD + dst0 - head);   // 16-byte aligned: slot bases and dst0 - head are
             const int g1 = min((part + 1) * n4p, n4);
             // the first / last group may hold up to 3 floats outside the span: they lie past the zero pad and no operand offset points at them
+#ifdef VG_EMU
             for (int g = part * n4p + lane; g < g1; g += VG_WAVE) {
                 mm_f4 t = v4[g];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t.v[e] = fmaf(vg_max(t.v[e], lo), sc, sh);
                 v4[g] = t;
             }
+#else
+            // LDS accesses as inline asm: in front of a ds_read the compiler can see, its wait-count pass puts s_waitcnt vmcnt(0) while an
+            // LDS-DMA is outstanding -- which also waits for every store of the previous unit (the counted wait above exists to avoid that)
+            for (int g = part * n4p + lane; g < g1; g += VG_WAVE) {
+                const unsigned a = (unsigned)(uintptr_t)(v4 + g);
+                vg_hw_f32x4 t;
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(a) : "memory");
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = fmaf(vg_max(t[e], lo), sc, sh);
+                asm volatile("ds_write_b128 %0, %1" :: "v"(a), "v"(t) : "memory");
+            }
+#endif
         }
+#ifndef VG_EMU
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the asm writes are invisible to the compiler's own wait in front of the barrier
+#endif
     };
     __syncthreads();
 #ifdef VG_STAMP
     unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
     VG_STAMP_T(st_last);
 #endif
-    if (DB && units > 0) stage(0);
+    if (units > 0) stage(0);
     int g_run = -1, n_run = 0;                                           // statistics: group / last sample of the running partial sums
+    int pend = 0;                                                        // single-buffered: stores issued AFTER the copy of the unit about to start
     for (int u = 0; u < units; ++u) {
         const int n = split + (u / nchunks) * p.nsplit, chunk = u % nchunks, c0 = chunk * d.cc;
         const int cc = min(d.cc, CI - c0);
         float* cur = In + (DB ? (u & 1) : 0) * p.buf_floats;
         VG_STAMP_ADD(7);
-        if (!DB) {
-            if (u > 0) __syncthreads();                                  // every wave has read the last operand of unit u-1
-            stage(u);
-        }
-        vg_dma_wait_wave();                                              // this wave's share of unit u has landed
+        if (DB) vg_dma_wait_wave();                                      // this wave's share of unit u has landed
+        else vg_wait_vm(pend);                                           // ... while the stores issued behind its copy keep draining
         VG_STAMP_ADD(0);
         if (p.has_pro) prologue(u);
         VG_STAMP_ADD(1);
@@ -372,16 +413,27 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
             if (chunk == 0) zero_acc();
             if (nact > 0) mm_dispatch<TPC>(nact, [&](auto ntc) __attribute__((always_inline)) { class_work(mm_int<0>{}, ntc); });
             VG_STAMP_ADD(4);
+            pend = 0;
+            if constexpr (!DB) {
+                // single buffer: the next unit's copy goes out as soon as every wave has read its last operand, AHEAD of this unit's stores
+                if (u + 1 < units) { __syncthreads(); VG_STAMP_ADD(2); stage(u + 1); VG_STAMP_ADD(3); }
+                if (chunk == nchunks - 1) pend = nst[0];
+            }
             if (chunk == nchunks - 1) store_class(n, 0);
             VG_STAMP_ADD(5);
         } else {
             // all channels are resident (the host plans one chunk per sample for multi-class layers)
             mm_static_for<NQ>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int q = decltype(qc)::value;
                 zero_acc();
                 VG_STAMP_ADD(5);
                 if (nact > 0) mm_dispatch<TPC>(nact, [&](auto ntc) __attribute__((always_inline)) { class_work(qc, ntc); });
                 VG_STAMP_ADD(4);
-                store_class(n, decltype(qc)::value);
+                if constexpr (!DB && q == NQ - 1) {                      // as above: copy of the next unit first, the last class's stores behind it
+                    if (u + 1 < units) { __syncthreads(); VG_STAMP_ADD(2); stage(u + 1); VG_STAMP_ADD(3); }
+                    pend = nst[q];
+                }
+                store_class(n, q);
             });
             VG_STAMP_ADD(5);
         }
@@ -448,6 +500,7 @@ extern "C" int vg_conv_mm(const vg_mm_desc* d, const float* x, const float* a_im
     if ((in_scale == nullptr) != (in_shift == nullptr) || (in_scale && d->per_group <= 0)) { vg_set_error("vg_conv_mm: in_scale/in_shift/per_group inconsistent"); return VG_ERR_ARG; }
     if (stats_part && (stats_per_group <= 0 || d->N % stats_per_group)) { vg_set_error("vg_conv_mm: bad statistics arguments"); return VG_ERR_ARG; }
     p.has_pro = (d->relu_in || in_scale) ? 1 : 0;
+    p.x4 = ((d->IH * d->IW) % 4 == 0 && ((uintptr_t)x % 16) == 0) ? 1 : 0;   // every plane span then starts and ends on a 16-byte boundary
     hipStream_t s = (hipStream_t)stream;
     // persistent grid = the blocks that are resident at once (occupancy query of the chosen instance x 256 CUs), dealt over the
     // bps position slabs of a sample: every further block of a slab takes every nsplit-th sample

@@ -1146,8 +1146,8 @@ def _mm_build(mode, S, pad, CI, CO, K, isz, osz, widx, force=None):
         assert NR == 2 and S == 2
         MDm = (KD + 1) // 2
         od0, oh0, ow0 = [], [], []
-        for rd in range(2):
-            for rh in range(2):
+        for rd, rh in (((0, 0), (1, 0), (0, 1), (1, 1)) if _os.environ.get('VG_MM_CLASS_ORDER') == 'h' else ((0, 0), (0, 1), (1, 0), (1, 1))):
+            if True:
                 ent = []
                 for md in range((KD - rd + 1) // 2):
                     for mh in range((KH - rh + 1) // 2):
