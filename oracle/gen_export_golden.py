@@ -160,6 +160,48 @@ def main():
         arrays['avg.%s.sub' % rel] = arr[::4, ::4, ::4].astype(np.float64)
         avg_keys.add(rel)
     arrays['avg_keys'] = np.array(sorted(avg_keys))
+
+    # ---- the yardstick: the same maps in FLOAT64 (oracle restatement on the reference model's own parameters, same noise).  A
+    # covariate map is gain x decoder output and the reference forms the gain in fp32 through a near-singular B x B Cholesky (SURVEY
+    # H2), so how far ITS fp32 maps sit from float64 is the scale on which a second implementation can be asked to agree with them:
+    # the test allows 3x this deviation (per statistic, per file) on top of the fp32 floor, as every other conditioning-limited check does.
+    import vaegam_oracle as O
+    cfg = O.OracleConfig(num_covariates=C, neural_covariates=True)
+    p = {'epsilon': model.epsilon.detach().clone()}
+    for gname, d_ in model.gp_params.items():
+        for k_, v_ in d_.items():
+            p['gp.%s.%s' % (gname, k_)] = v_.detach().clone()
+    for lname, layer in model._get_layers().items():
+        p[lname + '.weight'], p[lname + '.bias'] = layer.weight.detach().clone(), layer.bias.detach().clone()
+    glm_full = torch.from_numpy(np.concatenate([np.arange(int(np.prod(IMG)))[:, None].astype(np.float64), glm_df.to_numpy()], 1))
+    okeys = ['base'] + [c.name for c in cfg.schema] + ['full_rec']
+    fkeys = ['base', 'task', 'x_mot', 'y_mot', 'z_mot', 'pitch_mot', 'roll_mot', 'yaw_mot', 'sex', 'full_rec']   # the reference's file names, :327-342,605
+    maps64 = {k: np.zeros((T,) + (int(np.prod(IMG)),)) for k in fkeys}
+    for b in range(nb_):
+        sl = slice(b * BATCH, (b + 1) * BATCH)
+        noise = {'eps_w': tape.draws[b * per], 'eps_d': tape.draws[b * per + 1], 'eps_beta': torch.stack(tape.draws[b * per + 2:(b + 1) * per])}
+        p64, x64, c64, n64 = O.to_float64(p, torch.from_numpy(x[sl]), torch.from_numpy(cov[sl]), noise)
+        with torch.no_grad():
+            out64 = O.forward(p64, cfg, x64, c64, glm_full, n64)
+        for ok, fk in zip(okeys, fkeys):
+            maps64[fk][sl] = out64['maps'][ok].numpy()
+
+    def dev(ref_stats, m64, sub_ref=None):
+        s64 = stats(m64, vox)
+        d_ = [abs(ref_stats[0] - s64[0]), abs(ref_stats[1] - s64[1]), np.abs(ref_stats[2:] - s64[2:]).max()]
+        if sub_ref is not None:
+            d_.append(np.abs(sub_ref - m64.reshape(IMG)[::4, ::4, ::4]).max())
+        return np.array(d_)
+    for t in range(T):
+        for k in sorted(keys):
+            arrays['dev.vol.%d.%s' % (t, k)] = dev(arrays['vol.%d.%s' % (t, k)], maps64[k][t])
+    for rel in sorted(avg_keys):
+        k = os.path.basename(rel)[:-len('_avg')]
+        subj_avgs = [maps64[k][subj == s_].mean(0) for s_ in (0, 1)]
+        m64 = subj_avgs[int(rel[1])] if rel.startswith('s') and '/' in rel else (subj_avgs[0] + subj_avgs[1]) / 2       # build_model_recons.py:84-91
+        arrays['dev.avg.%s' % rel] = dev(arrays['avg.%s.stats' % rel], m64, arrays['avg.%s.sub' % rel])
+    worst = max((float(arrays[k_][2]), k_) for k_ in arrays if k_.startswith('dev.vol.'))
+    print('largest per-voxel distance of a reference map to float64: %.3g (%s)' % worst)
     print('maps per volume:', sorted(keys)); print('average maps:', sorted(avg_keys))
     np.savez_compressed(os.path.join(a.out, 'export_C8.npz'), **arrays)
     print('wrote', os.path.join(a.out, 'export_C8.npz'), os.path.getsize(os.path.join(a.out, 'export_C8.npz')), 'bytes')

@@ -115,6 +115,7 @@ def run_gam_case(dev, C, B, V, seed=0):
     gr = torch.autograd.grad((slp_r * g1).sum() + (dist_r * g2).sum(), tgt)
     dv = [logits.to(dev).clone().requires_grad_(True), gain.to(dev).clone().requires_grad_(True), x.to(dev), eps.to(dev).clone().requires_grad_(True), glm.to(dev)]
     lbias = torch.nn.Parameter(torch.zeros(1, device=dev))          # stands for the bias of the layer that produced the logits
+    lbias.grad = torch.zeros_like(lbias)                            # the caller binds the buffer the backward adds into (the optimiser does in the model)
     slp, dist = ops.GamElbo.apply(*dv, lbias)
     np.testing.assert_allclose(slp.detach().cpu().numpy(), slp_r.detach().numpy(), rtol=2e-5, atol=1e-3)
     np.testing.assert_allclose(dist.detach().cpu().numpy(), dist_r.detach().numpy(), rtol=2e-5, atol=1e-5)

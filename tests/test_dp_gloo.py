@@ -82,9 +82,11 @@ def test_two_ranks_equal_one_rank_global_batch(tmp_path):
 
 
 def test_local_gain_mode_draws_each_ranks_slice_from_its_own_covariance(tmp_path):
-    """dp_gain='local' (the default under data parallelism): a rank's gains are what ONE process draws for that rank's slice alone
-    (its own B x B gain covariance, its columns of the noise tape) -- no all-gather, cost independent of the number of ranks --
-    while batch-norm statistics, the loss normalisation and the gradient sum stay global: replicas remain identical."""
+    """dp_gain='local' (the default under data parallelism): a rank draws the gains of ITS slice from that slice's own B x B gain
+    covariance (its columns of the noise tape; the block-diagonal approximation of the joint draw, cost independent of the number of
+    ranks), and the HRF of the neural covariates then runs along the GLOBAL batch index across the slices (ops.HrfAcrossRanks) -- it
+    does not restart at a rank boundary.  Batch-norm statistics, the loss normalisation and the gradient sum stay global: replicas
+    remain identical."""
     port = _free_port()
     C = 8                                                        # the full covariate set (HRF on task, 6 GP regressors, sex) under data parallelism
     mp.spawn(_rank_main, args=(2, port, str(tmp_path), 'local', C), nprocs=2, join=True)
@@ -97,13 +99,50 @@ def test_local_gain_mode_draws_each_ranks_slice_from_its_own_covariance(tmp_path
     torch.randn(B_GLOBAL, 1, generator=gen); torch.randn(B_GLOBAL, 32, generator=gen)
     eps_beta = torch.randn(C, B_GLOBAL, generator=gen)
     b = B_GLOBAL // 2
+    # the ranks evaluated their gains AFTER one optimiser step: bring the single-process model to the same parameters
+    model.optimizer.groups[torch.float32]['p'].copy_(outs[0]['p'])
+    with torch.no_grad():
+        pre = torch.cat([model._gains(cov[r * b:(r + 1) * b][:, :C].float(), eps_beta[:, r * b:(r + 1) * b].contiguous(), hrf_in_kernel=False)[0]
+                         for r in range(2)], 1)                  # (C, B_GLOBAL): per-slice draws, not convolved
+        want = pre.clone()
+        hrf_rows = [i for i, c in enumerate(model.schema) if c.hrf]
+        assert hrf_rows == [0]
+        for i in hrf_rows:
+            want[i] = model.do_hrf_conv(pre[i])                  # ONE causal convolution along all B_GLOBAL volumes (vae_reg_GP.py:283-305)
+        restart = torch.cat([model.do_hrf_conv(pre[0, :b]), model.do_hrf_conv(pre[0, b:])])
+    assert float((want[0, b:] - restart[b:]).abs().max()) > 1e-3             # the case does tell the two apart
     for r in range(2):
-        sl = slice(r * b, (r + 1) * b)
-        # the ranks evaluated their gains AFTER one optimiser step: bring the single-process model to the same parameters
-        model.optimizer.groups[torch.float32]['p'].copy_(outs[r]['p'])
-        with torch.no_grad():
-            tv = model._gains(cov[sl][:, :C].float(), eps_beta[:, sl].contiguous())[0]
-        np.testing.assert_allclose(outs[r]['task_var'].numpy(), tv.numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(outs[r]['task_var'].numpy(), want[:, r * b:(r + 1) * b].numpy(), rtol=1e-5, atol=1e-6)
+
+
+def _hrf_rank(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from vae_gam_amd import dp as dpmod, ops
+    ctx = dpmod.DataParallelContext.from_env(backend='gloo')
+    g = torch.Generator().manual_seed(5)
+    Bg, Ch = 12, 2
+    b = Bg // world
+    pre_full = torch.randn(Ch, Bg, generator=g); w_full = torch.randn(Ch, Bg, generator=g); Tm = torch.randn(Bg, Bg, generator=g).triu()
+    pre = pre_full[:, rank * b:(rank + 1) * b].clone().requires_grad_(True)
+    out = ops.HrfAcrossRanks.apply(pre, Tm, ctx, rank * b)
+    (out * w_full[:, rank * b:(rank + 1) * b]).sum().backward()
+    torch.save({'out': out.detach(), 'g': pre.grad}, os.path.join(out_dir, 'hrf%d.pt' % rank))
+    ctx.shutdown()
+
+
+def test_hrf_across_ranks_forward_and_gradient_equal_the_global_convolution(tmp_path):
+    """ops.HrfAcrossRanks on 2 ranks == the (Bg, Bg) Toeplitz product of one process on the concatenated gains, forward and gradient
+    (the gradient of a rank's loss with respect to gains ANOTHER rank drew travels through the all-reduce)."""
+    port = _free_port()
+    mp.spawn(_hrf_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g = torch.Generator().manual_seed(5)
+    pre = torch.randn(2, 12, generator=g).requires_grad_(True); w = torch.randn(2, 12, generator=g); Tm = torch.randn(12, 12, generator=g).triu()
+    out = pre @ Tm
+    (out * w).sum().backward()
+    for r in range(2):
+        o = torch.load(os.path.join(tmp_path, 'hrf%d.pt' % r))
+        np.testing.assert_allclose(o['out'].numpy(), out.detach()[:, r * 6:(r + 1) * 6].numpy(), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(o['g'].numpy(), pre.grad[:, r * 6:(r + 1) * 6].numpy(), rtol=1e-6, atol=1e-6)
 
 
 def test_device_resident_data_shards_every_global_batch():

@@ -70,28 +70,30 @@ def test_exports_match_reference(tmp_path):
 
     vox = g['vox']
 
-    def check(path, want, what):
+    def check(path, want, what, dev):
         a = DataClass_GP.read_nifti1(path).astype(np.float64).ravel()
         got = np.concatenate([[a.sum(), (a * a).sum()], a[vox]])
-        # Maps are O(1) per voxel: 2e-5 absolute per voxel (maps 1e-5, + the fp32 file round trip).  A covariate map is
-        # gain x decoder output, and the gain block runs in fp64 here vs fp32 in the reference: its ABSOLUTE deviation (a few 1e-6) is
-        # a common factor of the whole map, i.e. up to 5e-5 relative on ordinary gains and 5e-4 on a gain that nearly cancels
-        # (vol 11, z_mot: gain 0.006).  Hence: per voxel relative 2e-4 OR absolute 2e-5; the sum over V voxels within V x 2e-5.
-        np.testing.assert_allclose(got[2:], want[2:], rtol=2e-4, atol=2e-5, err_msg=what)
-        np.testing.assert_allclose(got[0], want[0], rtol=2e-4, atol=2e-5 * a.size, err_msg=what + ' (sum)')
-        np.testing.assert_allclose(got[1], want[1], rtol=2e-3, atol=1e-3, err_msg=what + ' (sum of squares)')
+        # Bands = the fp32 floor of SURVEY 8c + 3x the distance of THE REFERENCE'S OWN fp32 file to the same map in float64, measured per
+        # file and statistic by the generator (`dev.*` in the fixture: [|sum|, |sum of squares|, max per voxel(, max over the strided
+        # sub-sample)]).  A covariate map is gain x decoder output and the reference draws the gain in fp32 through a near-singular B x B
+        # Cholesky -- up to 1.1e-4 per voxel from float64 on vol 11 / pitch_mot -- while the gain block here runs in fp64;
+        # the same rule as every other conditioning-limited comparison in tests/.  Floors: maps 1e-5 per voxel (+ the fp32 file round
+        # trip), the signed sum by the Cauchy-Schwarz bound 1e-5 * sqrt(sum of squares * V), the sum of squares rel 1e-4.
+        np.testing.assert_allclose(got[2:], want[2:], rtol=1e-5, atol=2e-5 + 3 * dev[2], err_msg=what)
+        np.testing.assert_allclose(got[0], want[0], rtol=1e-5, atol=1e-5 * np.sqrt(want[1] * a.size) + 3 * dev[0], err_msg=what + ' (sum)')
+        np.testing.assert_allclose(got[1], want[1], rtol=1e-4, atol=3 * dev[1], err_msg=what + ' (sum of squares)')
     root = tmp_path / 'reconstructions' / '007_model_recons'
     keys = [str(k) for k in g['map_keys']]
     for t in range(T):
         d = root / ('s%d' % subj[t]) / ('vol_%d' % vol[t])
         assert sorted(os.listdir(d)) == sorted('recon_%s.nii' % k for k in keys)
         for k in keys:
-            check(str(d / ('recon_%s.nii' % k)), g['vol.%d.%s' % (t, k)], 'vol %d %s' % (t, k))
+            check(str(d / ('recon_%s.nii' % k)), g['vol.%d.%s' % (t, k)], 'vol %d %s' % (t, k), g['dev.vol.%d.%s' % (t, k)])
     avg_root = tmp_path / 'reconstructions' / '007_avg_model_recons'
     avg_keys = [str(k) for k in g['avg_keys']]
     found = sorted(os.path.relpath(os.path.join(dp, f), str(avg_root))[:-4] for dp, _, fs in os.walk(str(avg_root)) for f in fs)
     assert found == sorted(avg_keys)
     for k in avg_keys:
-        check(str(avg_root / (k + '.nii')), g['avg.%s.stats' % k], 'avg ' + k)
+        check(str(avg_root / (k + '.nii')), g['avg.%s.stats' % k], 'avg ' + k, g['dev.avg.%s' % k])
         a = DataClass_GP.read_nifti1(str(avg_root / (k + '.nii')))
-        np.testing.assert_allclose(a[::4, ::4, ::4], g['avg.%s.sub' % k], rtol=2e-4, atol=2e-5, err_msg='avg ' + k)
+        np.testing.assert_allclose(a[::4, ::4, ::4], g['avg.%s.sub' % k], rtol=1e-5, atol=2e-5 + 3 * g['dev.avg.%s' % k][3], err_msg='avg ' + k)

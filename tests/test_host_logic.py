@@ -70,6 +70,45 @@ def test_seeded_model_matches_reference_parameter_order_and_checkpoint(small_ds,
     assert m2.gp_params['x']['qu_S'] is m2.qu_S_x
 
 
+def test_gp_jitter_travels_with_the_checkpoint_and_reaches_the_posterior_export(small_ds, tmp_path):
+    """gp_jitter (the Ku + jitter I remedy for dense inducing grids) is part of the model a checkpoint describes: saved as an extra key
+    when set, restored by load_state (which also drops the constants / graphs derived from the replaced state), exposed as --gp_jitter,
+    and used by gp.posterior_diag_batched -- the posterior plot_GPs exports is the one the training kernel evaluated."""
+    from vae_gam_amd import gp
+    torch.manual_seed(1)
+    m = VAE(num_covariates=8, glm_maps=small_ds['glm'], xu_ranges=small_ds['xu_ranges'], device_name='cpu', save_dir=str(tmp_path),
+            num_inducing_pts=64, gp_jitter=1e-4)
+    m.save_state('ckj.tar')
+    ck = torch.load(os.path.join(tmp_path, 'ckj.tar'), weights_only=False)
+    assert ck['gp_jitter'] == 1e-4
+    m2 = VAE(num_covariates=8, glm_maps=small_ds['glm'], xu_ranges=small_ds['xu_ranges'], device_name='cpu', save_dir=str(tmp_path),
+             num_inducing_pts=64)
+    m2._gain_const_cache['stale'] = object(); m2._graphs['stale'] = object()
+    m2.load_state(os.path.join(tmp_path, 'ckj.tar'))
+    assert m2.gp_jitter == 1e-4 and not m2._gain_const_cache and not m2._graphs
+    assert multsubj_reg_run_GP.build_parser().parse_args(['--gp_jitter', '1e-4']).gp_jitter == 1e-4
+    # 64 points on [-4, 6]: spacing 0.16 against a length scale of ~2 -- the plain inverse is garbage, the jittered posterior is not
+    xu = m.gp_params['x']['xu'].double().unsqueeze(0)
+    kv = torch.tensor([1.1], dtype=torch.float64); ls = torch.tensor([2.0], dtype=torch.float64)
+    qm = m.gp_params['x']['qu_m'].detach().double(); qS = m.gp_params['x']['qu_S'].detach().double().unsqueeze(0)
+    xq = torch.linspace(-3.5, 5.5, 50, dtype=torch.float64).unsqueeze(0)
+    fj, vj = gp.posterior_diag_batched(xu, kv, ls, qm, qS, xq, jitter=1e-4)
+    fb, Sg = gp.posterior_batched(xu, kv, ls, qm, qS, xq, jitter=1e-4)
+    np.testing.assert_allclose(fj.numpy(), fb.numpy(), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(vj.numpy(), Sg.diagonal(dim1=1, dim2=2).numpy(), rtol=1e-8, atol=1e-8)
+    # the same quantities from the definition, float64: A = Knu^T (Ku1 + jI)^-1, var = k_var + diag(A (S - k_var (Ku1 + jI)) A^T)
+    d = (xu[0].unsqueeze(1) - xq[0].unsqueeze(0))
+    k1 = lambda dist: torch.exp(-(dist / (np.sqrt(2) * 2.0)) ** 2)
+    ku = k1(xu[0].unsqueeze(0) - xu[0].unsqueeze(1)) + 1e-4 * torch.eye(64, dtype=torch.float64)
+    A = torch.linalg.solve(ku, k1(d)).T
+    # (the implementation rebuilds the grid as xu[0] + k*step like gp.py:92-94, this check uses the fp32-rounded grid points themselves:
+    #  1e-7 apart, times cond(Ku1 + jI) ~ 1e5)
+    np.testing.assert_allclose(fj[0].numpy(), (A @ qm[0]).numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(vj[0].numpy(), (1.1 + ((A @ (qS[0] - 1.1 * ku)) * A).sum(1)).numpy(), rtol=1e-4, atol=1e-4)
+    f0, _ = gp.posterior_diag_batched(xu, kv, ls, qm, qS, xq)            # the plain inverse on this grid: not a posterior
+    assert not np.allclose(f0.numpy(), fj.numpy(), rtol=1e-2, atol=1e-2)
+
+
 def test_checkpoint_loads_into_torch_adam(small_ds, tmp_path):
     """optimizer_state is torch.optim.Adam's own format: the reference's load_state can consume it."""
     torch.manual_seed(1)

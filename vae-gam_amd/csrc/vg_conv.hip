@@ -475,12 +475,11 @@ int launch_corr_plane(const vg_conv_desc* d, const float* x, const float* wpk, c
     p.TD = td; p.LD = (td * TDt - 1) * S + KD;
     p.tilesD = vg_cdiv(gd, p.TD);
     p.ch_floats = ((p.LD * plane + 63) / 64) * 64 + 64;  // slot per channel: whole 256-byte DMA groups + slack for window over-reads
-    // Optional (VG_PLANE_NBUF=2): two buffers, the next chunk in flight behind this chunk's FMAs, one barrier per chunk.
+    // Two buffers (the next chunk in flight behind this chunk's FMAs, one barrier per chunk) only for the large-tile instances.
     // Measured on MI355X: no gain where the chunk is small (convt3/convt4: 3 blocks per CU already hide the fill) and a
-    // loss where it doubles a 25 KB slot (convt5 forward 244 -> 341 us: only two 52 KB blocks fit a CU). Off by default.
-    static const int nbuf_env = getenv("VG_PLANE_NBUF") ? atoi(getenv("VG_PLANE_NBUF")) : 0;
+    // loss where it doubles a 25 KB slot (convt5 forward 244 -> 341 us: only two 52 KB blocks fit a CU).
     const size_t budget2 = (TDt * THt * TW > 16 ? 78 : 52) * 1024;      // two blocks per CU there (registers), three otherwise
-    p.nbuf = ((nbuf_env == 2 || TDt * THt * TW > 16) && d->CI > 1 && 2 * (size_t)p.ch_floats * sizeof(float) + (PLANE_SLACK + 64) * sizeof(float) <= budget2) ? 2 : 1;
+    p.nbuf = (TDt * THt * TW > 16 && d->CI > 1 && 2 * (size_t)p.ch_floats * sizeof(float) + (PLANE_SLACK + 64) * sizeof(float) <= budget2) ? 2 : 1;
     const size_t bud = p.nbuf == 2 ? budget2 : budget;
     int cch = (int)((bud - (PLANE_SLACK + 64) * sizeof(float)) / ((size_t)p.ch_floats * sizeof(float) * p.nbuf));
     if (cch < 1) cch = 1;
@@ -501,190 +500,6 @@ int launch_corr_plane(const vg_conv_desc* d, const float* x, const float* wpk, c
     vg_launch(corr3d_plane_k<COT, KD, KH, KW, S, TDt, THt, TW, COC>, grid, dim3(threads), shmem, s,
               x, wpk, bias, in_scale, in_shift, mask_src, y, p);
     return vg_check_launch("corr3d_plane");
-}
-
-// ------------------------------------------------------------------------------------------
-// corr3d on the matrix cores (layers with >= 8 input and >= 8 output channels).
-//   D[co][pos] += sum_k W[co][k] * X[k][pos],  k = (ci, tap), with the exact-fp32 v_mfma_f32_16x16x4_f32:
-//   A[co][kk] = W[co][ci][4 ks + kk]   (a [ci][ks][kk][co] LDS image built once per persistent block: ONE contiguous
-//                                       ds_read_b32 per k-step, shared by all position groups of the wave)
-//   B[kk][pos] = P(x)[ci][pos*S + tap - pad]   (one ds_read_b32 at  position offset + per-lane tap offset  out of the
-//                                       plane-staged input slot; ReLU / BN affine / zero-padding mask applied on the way)
-// A block owns up to 4*NG*16 consecutive flat output positions (whole planes); the input planes of ONE channel at a
-// time arrive by flat LDS-DMA, double-buffered over the channel loop; the accumulators (NG tiles per wave) live across
-// it.  Padding / overhang validity of every (position, tap) is folded into one bit mask per position group per item.
-// ------------------------------------------------------------------------------------------
-struct CorrMfmaParams {
-    vg_conv_desc d;
-    int TDO;                    // output planes per item
-    int LD;                     // input planes per item
-    int a_slot;                 // floats per input buffer
-    int w_off;                  // float offset of the weight image
-    int lds_floats;
-    int items, odblocks;
-};
-
-template <int KD, int KH, int KW, int S, int NG>
-__global__ void __launch_bounds__(256)
-corr3d_mfma_k(const float* __restrict__ x, const float* __restrict__ wpk, const float* __restrict__ bias,
-              const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-              const float* __restrict__ mask_src, float* __restrict__ y, CorrMfmaParams p) {
-    VG_DYN_SMEM(float, lds);
-    constexpr int KVOL = KD * KH * KW;
-    constexpr int KS = (KVOL + 3) / 4;
-    const vg_conv_desc& d = p.d;
-    const int CI = d.CI, CO = d.CO;
-    const int tid = threadIdx.x, lane = tid % VG_WAVE;
-    const int wave = vg_wave_id(), nwaves = blockDim.x / VG_WAVE;
-    const int kk = lane >> 4, jl = lane & 15;
-    const int plane = d.IH * d.IW, oplane = d.OH * d.OW;
-    float* wl = lds + p.w_off;
-
-    // (no LDS clear: every read of a never-written word is discarded by a select, never multiplied)
-    // ---- weight image wl[ci][ks][kk][co16] from the packed [ci][tap][co] weights (zero for tap >= KVOL, co >= CO)
-    //      (gathers in batches of 8 ahead of their LDS writes: a load -> wait -> write per iteration pays the memory latency 28 times)
-    for (int i0 = tid; i0 < CI * KS * 64; i0 += 8 * 256) {
-        float wv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * 256;
-            const int co = i & 15, k4 = (i >> 4) & 3, r = i >> 6;
-            const int ks = r % KS, ci = r / KS, tap = 4 * ks + k4;
-            wv[u] = (i < CI * KS * 64 && tap < KVOL && co < CO) ? wpk[((size_t)ci * KVOL + tap) * CO + co] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (i0 + u * 256 < CI * KS * 64) wl[i0 + u * 256] = wv[u];
-    }
-    // ---- per-lane tap geometry of k-step ks (tap = 4 ks + kk)
-    int tapOff[KS], tkd[KS], tkh[KS], tkw[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int tap = 4 * ks + kk;
-        const bool ok = tap < KVOL;
-        tkd[ks] = ok ? tap / (KH * KW) : -100000; tkh[ks] = ok ? (tap / KW) % KH : 0; tkw[ks] = ok ? tap % KW : 0;
-        tapOff[ks] = ok ? (tkd[ks] * d.IH + tkh[ks]) * d.IW + tkw[ks] : 0;
-    }
-    const float lo = d.relu_in ? 0.f : -__builtin_inff();
-    const size_t vol = (size_t)plane * d.ID, ovol = (size_t)oplane * d.OD;
-    __syncthreads();
-
-    for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
-        const int n = item / p.odblocks; const int od0 = (item % p.odblocks) * p.TDO;
-        const int g_aff = (in_scale != nullptr) ? n / d.per_group : 0;
-        const int npos = min(p.TDO, d.OD - od0) * oplane;
-        const int ip0 = od0 * S - d.pad_d;
-        const int pl_lo = max(ip0, 0), pl_hi = min(ip0 + p.LD, d.ID);
-        const int nfl = max(pl_hi - pl_lo, 0) * plane;
-        const int adst = (pl_lo - ip0) * plane;
-        const float* xbase = x + (size_t)n * CI * vol + (size_t)pl_lo * plane;
-        // ---- this lane's NG positions: LDS offset of tap 0 and the validity bits of its KS taps
-        int posOff[NG]; unsigned vm[NG]; int pfl[NG];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int pf = ((g * nwaves + wave) * 16) + jl;
-            pfl[g] = pf;
-            const bool pv = pf < npos;
-            const int pfc = pv ? pf : 0;
-            const int odl = pfc / oplane, r2 = pfc % oplane;
-            const int oh = r2 / d.OW, ow = r2 % d.OW;
-            const int idb = odl * S, ihb = oh * S - d.pad_h, iwb = ow * S - d.pad_w;     // d relative to ip0
-            posOff[g] = idb * plane + ihb * d.IW + iwb;
-            unsigned m = 0;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int id = ip0 + idb + tkd[ks], ih = ihb + tkh[ks], iw = iwb + tkw[ks];
-                const bool ok = pv && id >= 0 && id < d.ID && ih >= 0 && ih < d.IH && iw >= 0 && iw < d.IW;
-                m |= (ok ? 1u : 0u) << ks;
-            }
-            vm[g] = m;
-        }
-        vg_f32x4 acc[NG];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) { acc[g].v[0] = 0.f; acc[g].v[1] = 0.f; acc[g].v[2] = 0.f; acc[g].v[3] = 0.f; }
-
-        __syncthreads();                                                  // previous item done with the slots
-        for (int o = wave * VG_WAVE; o < nfl; o += blockDim.x)
-            if (o + lane < nfl) vg_dma4(xbase + o + lane, lds + adst + o);
-        vg_dma_wait();
-        __syncthreads();
-        for (int ci = 0; ci < CI; ++ci) {
-            const float* cur = lds + (ci & 1) * p.a_slot;
-            if (ci + 1 < CI) {
-                float* nxt = lds + ((ci + 1) & 1) * p.a_slot + adst;
-                const float* src = xbase + (size_t)(ci + 1) * vol;
-                for (int o = wave * VG_WAVE; o < nfl; o += blockDim.x)
-                    if (o + lane < nfl) vg_dma4(src + o + lane, nxt + o);
-            }
-            float sc = 1.f, sh = 0.f;
-            if (in_scale != nullptr) { sc = in_scale[g_aff * CI + ci]; sh = in_shift[g_aff * CI + ci]; }
-            const float* wci = wl + (size_t)ci * KS * 64 + lane;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const float aw = wci[ks * 64];
-                float bv[NG];
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    if ((g * nwaves + wave) * 16 >= npos) continue;       // wave-uniform: group past the item's end
-                    const bool ok = (vm[g] >> ks) & 1u;
-                    bv[g] = cur[ok ? posOff[g] + tapOff[ks] : 0];
-                }
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    if ((g * nwaves + wave) * 16 >= npos) continue;
-                    const bool ok = (vm[g] >> ks) & 1u;
-                    const float b_ = ok ? fmaf(vg_max(bv[g], lo), sc, sh) : 0.f;
-                    vg_mfma16(aw, b_, acc[g]);
-                }
-            }
-            vg_dma_wait();
-            __syncthreads();
-        }
-        // ---- epilogue: lane owns position pfl[g], channels co = kk*4 + r
-        float* yb = y + (size_t)n * CO * ovol + (size_t)od0 * oplane;
-        const float* mb = mask_src ? mask_src + (size_t)n * CO * ovol + (size_t)od0 * oplane : nullptr;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (pfl[g] >= npos) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = kk * 4 + r;
-                if (co >= CO) continue;
-                float v = acc[g].v[r] + (bias ? bias[co] : 0.f);
-                if (mb) v = (mb[(size_t)co * ovol + pfl[g]] > 0.f) ? v : 0.f;
-                yb[(size_t)co * ovol + pfl[g]] = v;
-            }
-        }
-    }
-}
-
-// returns -1 when the geometry does not fit (caller falls back to the VALU kernels)
-template <int KD, int KH, int KW, int S, int NG>
-int launch_corr_mfma(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias, const float* in_scale,
-                     const float* in_shift, const float* mask_src, float* y, hipStream_t s) {
-    constexpr int KVOL = KD * KH * KW;
-    constexpr int KS = (KVOL + 3) / 4;
-    if (d->CO > 16) return -1;
-    CorrMfmaParams p; p.d = *d;
-    const int oplane = d->OH * d->OW, plane = d->IH * d->IW;
-    const int cap = 4 * NG * 16;                                  // positions per block
-    if (oplane > cap) return -1;
-    p.TDO = cap / oplane; if (p.TDO > d->OD) p.TDO = d->OD;
-    while (p.TDO > 1 && (long)d->N * vg_cdiv(d->OD, p.TDO) < 256) --p.TDO;      // at least one item per CU
-    const size_t budget = 60 * 1024;
-    auto slot_for = [&](int LD) { return (((size_t)(LD + 1) * plane + (size_t)KH * d->IW + 8 * S + 64 + 63) / 64) * 64; };
-    const size_t wfl = (size_t)d->CI * KS * 64;
-    while (p.TDO >= 1 && (2 * slot_for((p.TDO - 1) * S + KD) + wfl + 64) * 4 > budget) --p.TDO;
-    if (p.TDO < 1) return -1;
-    p.LD = (p.TDO - 1) * S + KD;
-    p.a_slot = (int)slot_for(p.LD);
-    p.w_off = 2 * p.a_slot;
-    p.lds_floats = (int)(p.w_off + wfl + 64);
-    p.odblocks = vg_cdiv(d->OD, p.TDO);
-    p.items = d->N * p.odblocks;
-    const int grid = p.items < 1024 ? p.items : 1024;
-    vg_launch(corr3d_mfma_k<KD, KH, KW, S, NG>, dim3(grid), dim3(256), (size_t)p.lds_floats * sizeof(float), s,
-              x, wpk, bias, in_scale, in_shift, mask_src, y, p);
-    return vg_check_launch("corr3d_mfma");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -917,10 +732,6 @@ static int check_desc(const vg_conv_desc* d, const void* x, const void* w, const
     return VG_OK;
 }
 
-// vg_conv_mfma.hip: stride-1 3x3x3 layers on the matrix cores; -1 = geometry not covered
-int vg_corr3d_s1_mfma(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias, const float* in_scale,
-                      const float* in_shift, const float* mask_src, float* y, hipStream_t s);
-
 extern "C" int vg_corr3d(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias,
                          const float* in_scale, const float* in_shift, const float* mask_src, float* y, void* stream) {
     int rc = check_desc(d, x, wpk, y, "vg_corr3d");
@@ -950,24 +761,15 @@ extern "C" int vg_corr3d(const vg_conv_desc* d, const float* x, const float* wpk
              : launch_corr_plane<COT, KD, KH, KW, S, TDt, THt, TW, 0>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); \
       if (r_ >= 0) return r_; \
       return launch_corr<COT, KD, KH, KW, S, TDt, THt, TW>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); }
-    if (!getenv("VG_NO_S1M")) { int r_ = vg_corr3d_s1_mfma(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); if (r_ >= 0) return r_; }
 #define CORR_LDS_RT(COT, KD, KH, KW, S, TDt, THt, TW) /* run-time channel count: measured faster for the 3x3x3 stride-1 8-wide instance */ \
     { int r_ = launch_corr_plane<COT, KD, KH, KW, S, TDt, THt, TW, 0>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); \
       if (r_ >= 0) return r_; \
-      if (d->CO == COT && !getenv("VG_DIRECT_RT")) return launch_corr<COT, KD, KH, KW, S, TDt, THt, TW, COT>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); \
+      if (d->CO == COT) return launch_corr<COT, KD, KH, KW, S, TDt, THt, TW, COT>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); \
       return launch_corr<COT, KD, KH, KW, S, TDt, THt, TW>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); }
-#define CORR_MFMA(KD, KH, KW, S) \
-    if (d->CI > 8 && d->CO > 8 && !getenv("VG_NO_MFMA_CONV")) { int r_ = launch_corr_mfma<KD, KH, KW, S, 8>(d, x, wpk, bias, in_scale, in_shift, mask_src, y, s); if (r_ >= 0) return r_; }
-    if (k333 && d->stride == 1) CORR_MFMA(3, 3, 3, 1)
-    if (k333 && d->stride == 2) CORR_MFMA(3, 3, 3, 2)
-    if (d->KD == 5 && d->KH == 3 && d->KW == 3 && d->stride == 2) CORR_MFMA(5, 3, 3, 2)
-    if (d->KD == 4 && d->KH == 4 && d->KW == 4 && d->stride == 2) CORR_MFMA(4, 4, 4, 2)
-#undef CORR_MFMA
     if (k333 && d->stride == 1) {
         // one output channel (the decoder's last layer): 4x2x4 outputs per thread, 6 input planes per 4 output planes (input fetched
         // 1.5x instead of 2x), two blocks per CU with the next channel's planes in flight: 803 -> 735 us at batch 64 / 8 covariates
-        if (d->CO == 1 && !getenv("VG_C5_TDT2")) CORR_LDS(1, 3, 3, 3, 1, 4, 2, 4);
-        if (d->CO == 1) CORR_LDS(1, 3, 3, 3, 1, 2, 2, 4);
+        if (d->CO == 1) CORR_LDS(1, 3, 3, 3, 1, 4, 2, 4);
         if (d->CO % 8 == 0 && !small) CORR_LDS_RT(8, 3, 3, 3, 1, 1, 1, 4);
         if (d->CO % 4 == 0 && small) CORR(4, 3, 3, 3, 1, 1, 1, 2);
     }

@@ -728,6 +728,14 @@ int launch_plane(const vg_wgrad_desc* d, const float* a, const float* b, const f
 #ifndef VG_WG_MINB
 #define VG_WG_MINB 1
 #endif
+#ifdef VG_STAMP
+// Diagnostic build only (tools/diag): per-wave cycle sums of wgrad_rows_k's phases, read back through vg_stamp_read_wg.
+__device__ unsigned long long vg_wg_stamp_out[2048 * 4 * 8];
+#define VG_WS_T(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define VG_WS_ADD(i) do { unsigned long long t_; VG_WS_T(t_); st_sum[i] += t_ - st_last; st_last = t_; } while (0)
+#else
+#define VG_WS_ADD(i) do {} while (0)
+#endif
 template <int V> struct vg_int { static constexpr int value = V; };
 template <int N, int I = 0, typename F>
 __host__ __device__ inline void vg_static_for(F&& f) { if constexpr (I < N) { f(vg_int<I>{}); vg_static_for<N, I + 1>(f); } }
@@ -832,6 +840,10 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
     const int it0 = GRP ? ((int)blockIdx.x / p.ipb) * p.grp_items + (int)blockIdx.x % p.ipb : (int)blockIdx.x;
     const int it1 = GRP ? ((int)blockIdx.x / p.ipb + 1) * p.grp_items : p.items;
 
+#ifdef VG_STAMP
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+    VG_WS_T(st_last);
+#endif
     for (int item = it0; item < it1; item += it_step) {
         const int n = item / (p.pdblocks * p.nph); const int rem = item % (p.pdblocks * p.nph);
         const int pd0 = (rem / p.nph) * p.TPD, ph0 = (rem % p.nph) * p.TPH;
@@ -847,7 +859,9 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
         float bsc = cb_ok ? 1.f : 0.f, bsh = 0.f;                        // lanes without a b channel contribute zeros
         if (!PA && in_scale && cb_ok) { bsc = in_scale[g * CB + cbl]; bsh = in_shift[g * CB + cbl]; }
         if (GRP && cbl == CB) bsh = 1.f;                                 // ones row (bsc stays 0: the lane reads channel CB-1's finite data)
+        VG_WS_ADD(0);                                                     // item set-up
         __syncthreads();                                                  // previous item's tiles fully consumed
+        VG_WS_ADD(1);                                                     // barrier (item start)
         // one (channel, plane) span per wave at a time: the span's base addresses are formed once, the 256-byte DMA
         // instructions of the span then cost a handful of scalar adds each (a flattened loop pays two scalar divisions
         // and 64-bit address arithmetic -- ~75 SALU instructions -- per DMA instruction)
@@ -870,8 +884,11 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
                 for (int dz = 0; dz < ndz; ++dz, src += bplane, dst += p.TPH * d.PW) vg_dma_span(src, dst, nb, lane);
             }
         }
+        VG_WS_ADD(2);                                                     // copy issue (a slot 0 + b tile)
         vg_dma_wait();
+        VG_WS_ADD(3);                                                     // copy wait
         __syncthreads();
+        VG_WS_ADD(1);
         // one position row against one `a` channel: UG k-steps per iteration, all operand reads first, then the matrix
         // instructions.  ONE branch-free loop whose trip count is rounded up to UG (surplus k-steps have px >= PW: their A
         // operand is zeroed, their reads stay inside the tiles' slack); only the LAST block can hold such positions and it
@@ -941,6 +958,7 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
                 constexpr int ca = decltype(ca_tag)::value;
                 const float* cur = lds + (ca % p.nbuf) * p.a_slot;
                 if (ca + 1 < CA && p.nbuf == 2) stage_a(ca + 1, 1, (ca + 1) & 1);    // in flight behind this channel's MFMAs
+                VG_WS_ADD(4);                                                     // copy issue (next channel)
                 float sc = 1.f, sh = 0.f;
                 if (PA && in_scale) { sc = in_scale[g * CA + ca]; sh = in_shift[g * CA + ca]; }
                 // rows of the tile dealt round-robin over the 4 waves ((plane, row) wave-uniform: scalars, no division)
@@ -952,15 +970,26 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
                     row_masks(dz, py, okdh);
                     row_channel(ca_tag, bp, ap, sc, sh, okdh);
                 }
+                VG_WS_ADD(5);                                                     // matrix work of a channel
                 if (CA > 1) {
-                    if (p.nbuf == 2) { vg_dma_wait(); __syncthreads(); }
+                    if (p.nbuf == 2) { vg_dma_wait(); VG_WS_ADD(6); __syncthreads(); VG_WS_ADD(7); }
                     else if (ca + 1 < CA) { __syncthreads(); stage_a(ca + 1, 1, 0); vg_dma_wait(); __syncthreads(); }
                 }
             });
         }
     }
+#ifdef VG_STAMP
+    if (lane == 0 && blockIdx.x < 2048)
+        for (int i = 0; i < 8; ++i) vg_wg_stamp_out[(blockIdx.x * 4 + wave) * 8 + i] = st_sum[i];
+#endif
     write_out((int)blockIdx.x);
 }
+
+#ifdef VG_STAMP
+extern "C" int vg_stamp_read_wg(unsigned long long* dst, int n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(vg_wg_stamp_out), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // Slabs of a grouped launch -> out[g][len]: group g owns the slabs [g*spg, (g+1)*spg)
 __global__ void __launch_bounds__(64 * SLAB_ROWS)
@@ -991,13 +1020,12 @@ int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const fl
     if (padded != PAD || d->CA != CA || d->CB > 16) return -1;
     const bool narrow = d->PW < 12;                 // 5..7-position rows: only worth it with every channel resident (rows outermost)
     if (!PAD && ((d->PD - 1) * S + KD > d->AD || (d->PH - 1) * S + KH > d->AH || (d->PW - 1) * S + KW > d->AW)) return -1;
-    static const long cap_env = getenv("VG_WGRAD_LDS") ? atol(getenv("VG_WGRAD_LDS")) : 0;
-    // LDS per block: measured sweep (tools/layer_bench.py, VG_WGRAD_LDS): 56 KB is best or equal for every layer of the net
+    // LDS per block: measured sweep (tools/layer_bench.py over a build-time cap): 56 KB is best or equal for every layer of the net
     // (convt4 212 -> 187 us, convt2 104 -> 92, convt5 130 -> 119 vs 24-48 KB); 64 KB leaves one block per CU too few
     // (measured and NOT adopted: compiling the 16-24-tile instances for three waves per SIMD (-DVG_WG_MINB=3, 166 registers, no spills) with
     //  48 KB tiles is 6 % faster per layer in tools/layer_bench.py -- convt4 799 -> 753 us, convt3 345 -> 326 -- but not in the step, where these
     //  launches share the GPU with the gain block's backward on the second stream: 8.17-8.22 vs 8.21-8.24 ms)
-    const size_t cap = cap_env > 0 ? (size_t)cap_env : (size_t)56 * 1024;
+    const size_t cap = (size_t)56 * 1024;
     (void)narrow;
     const size_t red_fl = (size_t)NT * 4 * VG_WAVE;
     const int front = 4;                            // >= pad_w: the first window of a padded row starts before the slot's row
@@ -1058,8 +1086,6 @@ int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const fl
     }
     int per_cu = vg_blocks_per_cu((const void*)kern, 256, fl * sizeof(float));   // persistent grid == resident blocks
     if (per_cu > 8) per_cu = 8;
-    { static const int cap_blocks = getenv("VG_WGRAD_BLOCKS_PER_CU") ? atoi(getenv("VG_WGRAD_BLOCKS_PER_CU")) : 0;
-      if (cap_blocks > 0 && per_cu > cap_blocks) per_cu = cap_blocks; }
     int grid = 256 * per_cu; if (grid > p.items) grid = p.items;
     p.grp_items = 0; p.ipb = 0; p.ones_row = 0;
     if (grouped) {
@@ -1194,12 +1220,12 @@ int dispatch(const vg_wgrad_desc* d, const float* a, const float* b, const float
     const bool k333 = d->KD == 3 && d->KH == 3 && d->KW == 3;
     const bool small_w = d->PW <= 8;
 #define PLANE(CA, TC, KD, KH, KW, S) \
-    { if (!getenv("VG_NO_WGRAD_ROWS")) { int r_ = launch_rows<CA, TC, KD, KH, KW, S, false>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; } \
+    { { int r_ = launch_rows<CA, TC, KD, KH, KW, S, false>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; } \
       int r_ = launch_plane<CA, TC, KD, KH, KW, S, false>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; }
     if (d->CB <= 16 && d->PW <= 64) {
         if (k333 && d->CA == 1 && d->stride == 1) PLANE(1, 2, 3, 3, 3, 1);
         if (k333 && d->CA == 16 && d->stride == 2 && (d->pad_d || d->pad_h || d->pad_w))
-            { if (!getenv("VG_NO_WGRAD_ROWS")) { int r_ = launch_rows<16, 2, 3, 3, 3, 2, true>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; }
+            { { int r_ = launch_rows<16, 2, 3, 3, 3, 2, true>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; }
               int r_ = launch_plane<16, 2, 3, 3, 3, 2, true>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; }
         if (k333 && d->CA == 8 && d->stride == 1) PLANE(8, 2, 3, 3, 3, 1);
         if (k333 && d->CA == 8 && d->stride == 2) PLANE(8, 2, 3, 3, 3, 2);

@@ -23,7 +23,18 @@ def striped_matrix(n, device=None, dtype=torch.float32):
     return (idx.unsqueeze(0) - idx.unsqueeze(1)).abs()
 
 
-def posterior_batched(xu, k_var, ls, qu_m, qu_S, xq):
+def _ku1_inverse(ku1, jitter):
+    """inverse of the unit-variance inducing kernel matrix: the reference's plain inverse (gp.py:107), or -- jitter > 0, the remedy for
+    grids that are dense against the length scale -- of Ku1 + jitter I through its Cholesky factor, as vg_gp_gain_fwd does."""
+    if not jitter:
+        return torch.linalg.inv_ex(ku1, check_errors=False).inverse, ku1
+    n = ku1.shape[-1]
+    kuj = ku1 + float(jitter) * torch.eye(n, device=ku1.device, dtype=ku1.dtype)
+    L = torch.linalg.cholesky(kuj)
+    return torch.cholesky_inverse(L), kuj
+
+
+def posterior_batched(xu, k_var, ls, qu_m, qu_S, xq, jitter=0.0):
     """q(f) for K independent 1-D GPs at once.
 
     xu (K,n) inducing grids, k_var (K,), ls (K,), qu_m (K,n), qu_S (K,n,n), xq (K,B) query points.
@@ -35,7 +46,8 @@ def posterior_batched(xu, k_var, ls, qu_m, qu_S, xq):
     step = (xu[:, 1] - xu[:, 0]).detach()
     d0 = xu[:, 0].detach().double().unsqueeze(1) - xq.detach().double()                    # (K,B)
     kidx = torch.arange(n, device=xu.device, dtype=torch.float64)
-    knu_d = (d0.unsqueeze(1) + kidx.view(1, n, 1) * step.double().view(K, 1, 1)).float().to(xq.dtype)   # (K,n,B); fp32-rounded as gp.py:90
+    knu_d = d0.unsqueeze(1) + kidx.view(1, n, 1) * step.double().view(K, 1, 1)                         # (K,n,B)
+    knu_d = (knu_d if jitter else knu_d.float()).to(xq.dtype)          # fp32-rounded as gp.py:90; the jittered form keeps float64 distances
     kv, l_ = k_var.view(K, 1, 1), ls.view(K, 1, 1)
     one = torch.ones((), device=xu.device, dtype=xq.dtype)
     step = step.to(xq.dtype)
@@ -46,14 +58,14 @@ def posterior_batched(xu, k_var, ls, qu_m, qu_S, xq):
     knu1 = distance_to_kernel(knu_d, one, l_)
     knn1 = distance_to_kernel(xq.unsqueeze(1) - xq.unsqueeze(2), one, l_)                   # [k,i,j] = xq_j - xq_i
     ku1 = distance_to_kernel(striped_matrix(n, xu.device, xq.dtype).unsqueeze(0) * step.view(K, 1, 1), one, l_)
-    ku1_inv = torch.linalg.inv_ex(ku1, check_errors=False).inverse
+    ku1_inv, ku1 = _ku1_inverse(ku1, jitter)                                               # jitter: the inducing prior is k_var (Ku1 + jitter I)
     A = knu1.transpose(1, 2) @ ku1_inv                                                      # (K,B,n)
     f_bar = (A @ qu_m.unsqueeze(-1)).squeeze(-1)
     Sigma = kv * knn1 + A @ (qu_S - kv * ku1) @ A.transpose(1, 2)
     return f_bar, Sigma
 
 
-def posterior_diag_batched(xu, k_var, ls, qu_m, qu_S, xq):
+def posterior_diag_batched(xu, k_var, ls, qu_m, qu_S, xq, jitter=0.0):
     """Posterior mean and VARIANCE (diagonal of Sigma only) of K independent 1-D GPs at N query points each:
     f_bar (K,N), var (K,N) = k_var + rowsum((A M) * A), M = qu_S - k_var Ku1, in O(N n^2) time and O(N n) memory.
     The full-data-set export (vae_reg_GP.py:641-673) asks the reference for the N x N covariance of ALL volumes and
@@ -62,13 +74,14 @@ def posterior_diag_batched(xu, k_var, ls, qu_m, qu_S, xq):
     step = (xu[:, 1] - xu[:, 0]).detach()
     d0 = xu[:, 0].detach().double().unsqueeze(1) - xq.detach().double()
     kidx = torch.arange(n, device=xu.device, dtype=torch.float64)
-    knu_d = (d0.unsqueeze(1) + kidx.view(1, n, 1) * step.double().view(K, 1, 1)).float().to(xq.dtype)
+    knu_d = d0.unsqueeze(1) + kidx.view(1, n, 1) * step.double().view(K, 1, 1)
+    knu_d = (knu_d if jitter else knu_d.float()).to(xq.dtype)
     kv, l_ = k_var.view(K, 1, 1), ls.view(K, 1, 1)
     one = torch.ones((), device=xu.device, dtype=xq.dtype)
     step = step.to(xq.dtype)
     knu1 = distance_to_kernel(knu_d, one, l_)
     ku1 = distance_to_kernel(striped_matrix(n, xu.device, xq.dtype).unsqueeze(0) * step.view(K, 1, 1), one, l_)
-    ku1_inv = torch.linalg.inv_ex(ku1, check_errors=False).inverse
+    ku1_inv, ku1 = _ku1_inverse(ku1, jitter)                                               # the posterior the model TRAINED (VAE.gp_jitter)
     A = knu1.transpose(1, 2) @ ku1_inv                                                      # (K,N,n)
     f_bar = (A @ qu_m.unsqueeze(-1)).squeeze(-1)
     var = k_var.view(K, 1) + ((A @ (qu_S - kv * ku1)) * A).sum(-1)                          # k(0) = 1 for the unit kernel

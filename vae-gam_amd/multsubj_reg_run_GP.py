@@ -42,6 +42,9 @@ def build_parser():
     parser.add_argument('--recons_only', type=str2bool, nargs='?', const=True, default=False, help='Skip training.')
     parser.add_argument('--neural_covariates', type=str2bool, nargs='?', const=True, default=True,
                         help='Covariate set includes neural/biological effects to be convolved with the HRF.')
+    parser.add_argument('--gp_jitter', type=float, metavar='N', default=0.0,
+                        help='(extension) Ku + jitter*I in the GP posteriors; 0 = the reference\'s plain inverse. Needed for dense inducing grids '
+                             '(e.g. --num_inducing_pts 64: 1e-4), where Ku is singular in any precision.')
     return parser
 
 
@@ -60,17 +63,18 @@ def main(argv=None):
     rank = 0 if dp is None else dp.rank
     if dp is not None and args.batch_size % dp.world_size:
         raise SystemExit('--batch-size %d (the GLOBAL minibatch) must be a multiple of the %d ranks' % (args.batch_size, dp.world_size))
-    # the reference's loaders (whole data set, global minibatch): what the export pipeline iterates; under data parallelism the
-    # train / test loops get re-built loaders that hand each rank its slice of every global minibatch
+    # the reference's loaders (whole data set, GLOBAL minibatch, multsubj_reg_run_GP.py:69): what the export pipeline iterates -- gains
+    # (joint draw, HRF along the batch) and the decoder's batch statistics depend on the batch composition, so the exported maps must
+    # see the batches a single process would; under data parallelism the train / test loops get re-built loaders that hand each rank
+    # its slice of every global minibatch (they only take the data sets from these)
     # (single process on a GPU: minibatches are staged in pinned memory and copied one batch ahead on a side stream)
-    full_loaders = data.setup_data_loaders(batch_size=args.batch_size if dp is None else args.batch_size // dp.world_size,
-                                           train_csv=args.train_csv, test_csv=args.test_csv,
+    full_loaders = data.setup_data_loaders(batch_size=args.batch_size, train_csv=args.train_csv, test_csv=args.test_csv,
                                            prefetch_device='cuda' if (dp is None and torch.cuda.is_available()) else None)
     loaders_dict = full_loaders if dp is None else dp.shard_loaders(full_loaders, args.batch_size, args.seed)
     model = vae_reg.VAE(num_inducing_pts=args.num_inducing_pts, gp_kl_scale=args.gp_kl_scale,
                         glm_reg_scale=args.glm_reg_scale, glm_maps=args.glm_maps, save_dir=args.save_dir,
                         csv_files=[args.train_csv, args.test_csv], neural_covariates=args.neural_covariates,
-                        data_parallel=dp, dp_gain=os.environ.get('VG_DP_GAIN', 'local'))   # 'global': exact global-batch gain draw
+                        data_parallel=dp, dp_gain=os.environ.get('VG_DP_GAIN', 'local'), gp_jitter=args.gp_jitter)
     if args.from_ckpt:
         assert os.path.exists(args.ckpt_path), 'Oops, looks like ckpt file given does NOT exist!'
         print('=' * 40)
@@ -89,22 +93,23 @@ def main(argv=None):
 
 def export_outputs(model, loaders_dict, args, dp=None):
     """The post-training block of the reference wrapper (multsubj_reg_run_GP.py:83-86 and, for --recons_only, :89-92), on
-    the training set.  Rank 0 only under data parallelism: the replicas are identical, and the export runs single-process
-    (model.dp detached for its duration) while the other ranks wait at a barrier."""
+    the training set.  Rank 0 only under data parallelism: the replicas are identical and the export runs single-process.  The
+    process group is torn down FIRST (after one barrier): the other ranks return instead of sitting in a collective for as long as
+    the export takes (file output of every volume x map: minutes on a real data set, past the RCCL watchdog's patience)."""
     from . import build_model_recons as recon
     if dp is not None:
         dp.barrier()
-    if dp is None or dp.rank == 0:
-        saved_dp, model.dp = model.dp, None
-        try:
-            print('project_latent (UMAP plot of the latent space, vae_reg_GP.py:542-583) is not part of this build: skipped.')
-            model.plot_GPs(csv_file=args.train_csv, save_dir=args.save_dir)
-            recon.mk_single_volumes(loaders_dict['UnShuffled_train'], model, args.train_csv, args.save_dir)
-            recon.mk_avg_maps(args.train_csv, model, args.save_dir, mk_motion_maps=True)
-        finally:
-            model.dp = saved_dp
-    if dp is not None:
-        dp.barrier()
+        dp.shutdown()
+        if dp.rank != 0:
+            return
+    saved_dp, model.dp = model.dp, None
+    try:
+        print('project_latent (UMAP plot of the latent space, vae_reg_GP.py:542-583) is not part of this build: skipped.')
+        model.plot_GPs(csv_file=args.train_csv, save_dir=args.save_dir)
+        recon.mk_single_volumes(loaders_dict['UnShuffled_train'], model, args.train_csv, args.save_dir)
+        recon.mk_avg_maps(args.train_csv, model, args.save_dir, mk_motion_maps=True)
+    finally:
+        model.dp = saved_dp
 
 
 if __name__ == "__main__":

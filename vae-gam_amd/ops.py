@@ -604,7 +604,9 @@ class BnConvAct(torch.autograd.Function):
             if ctx.producer_bias is not None:
                 pb = ctx.producer_bias
                 if pb.grad is None:
-                    pb.grad = torch.zeros_like(pb)
+                    # allocating here would leave the gradient OUTSIDE the flat buffer the optimiser and the all-reduce read
+                    raise RuntimeError('bn_conv_act: producer_bias.grad is not bound -- the consumer adds the producer\'s bias gradient into it '
+                                       '(FusedAdam binds every .grad to its flat buffer; a free-standing caller sets .grad = zeros first)')
                 pbg = pb.grad
             if fuse_last:
                 # the data gradient is recomputed inside the batch-norm backward pass(es), never stored
@@ -700,7 +702,7 @@ class GamElbo(torch.autograd.Function):
             pb = ctx.logits_bias
             assert pb.numel() == 1
             if pb.grad is None:
-                pb.grad = torch.zeros_like(pb)
+                raise RuntimeError('GamElbo: logits_bias.grad is not bound (see bn_conv_act: the bias gradient is added into the caller\'s buffer)')
             tot = pb.grad
         G, B, V = logits.shape
         C = G - 1
@@ -1000,6 +1002,31 @@ class GpGain(torch.autograd.Function):
         return (None,) * len(ctx.needs_input_grad)
 
 
+class HrfAcrossRanks(torch.autograd.Function):
+    """Data parallel, dp_gain='local': the causal HRF convolution along the GLOBAL batch index (vae_reg_GP.py:283-305, 377-378) of
+    gains that every rank drew for its own slice.  Forward: all-gather the pre-HRF gains of the HRF covariates ((Ch, B) -> (Ch, Bg):
+    a few hundred floats), multiply by the (Bg, Bg) Toeplitz matrix of the 15 taps, keep this rank's columns.  Backward: a rank's
+    loss also depends on the up to 14 volumes in front of its slice, which another rank drew -- the gradient with respect to the
+    gathered gains is summed over ranks (one tiny all-reduce) and each rank keeps the columns it drew.  Without this the
+    convolution would restart at every slice boundary."""
+
+    @staticmethod
+    def forward(ctx, pre, T, dp, lo):
+        B = pre.shape[1]
+        full = dp.all_gather_rows(pre.t().contiguous()).t()             # (Ch, Bg), rank order = batch order
+        ctx.save_for_backward(T)
+        ctx.dp, ctx.lo, ctx.B = dp, int(lo), int(B)
+        return (full @ T)[:, lo:lo + B].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        (T,) = ctx.saved_tensors
+        lo, B = ctx.lo, ctx.B
+        gp = g.contiguous() @ T[:, lo:lo + B].t()                       # (Ch, Bg): d(this rank's loss) / d(every pre-HRF gain it used)
+        gp = ctx.dp.allreduce_sum_(gp)
+        return gp[:, lo:lo + B].contiguous(), None, None, None
+
+
 def adam_advance_(state, lr, b1, b2):
     """state = double[3] {lr/(1-b1^t), sqrt(1-b2^t), t} on the device: t += 1, scalars refreshed (one thread)."""
     _call(state, 'vg_adam_advance', _p(_chk(state, torch.float64)), float(lr), float(b1), float(b2))
@@ -1146,7 +1173,7 @@ def _mm_build(mode, S, pad, CI, CO, K, isz, osz, widx, force=None):
         assert NR == 2 and S == 2
         MDm = (KD + 1) // 2
         od0, oh0, ow0 = [], [], []
-        for rd, rh in (((0, 0), (1, 0), (0, 1), (1, 1)) if _os.environ.get('VG_MM_CLASS_ORDER') == 'h' else ((0, 0), (0, 1), (1, 0), (1, 1))):
+        for rd, rh in ((0, 0), (0, 1), (1, 0), (1, 1)):
             if True:
                 ent = []
                 for md in range((KD - rd + 1) // 2):
@@ -1227,9 +1254,6 @@ def _mm_build(mode, S, pad, CI, CO, K, isz, osz, widx, force=None):
                 cands.append((score, PD, LD, cc, tpc, dbuf))
     if not cands:
         return None
-    if _os.environ.get('VG_MM_DEBUG'):
-        for c in sorted(cands, reverse=True)[:6]:
-            print('mm_plan cand', mode, CI, CO, isz, c)
     _, PD, LD, cc, tpc, dbuf = max(cands, key=lambda c: (round(c[0], 9), c[3], -c[5]))
     tpc = {1: (3 if tpc <= 3 else tpc if tpc <= 6 else 8), 4: 4}[nq]
     return MmPlan(CI=CI, CO=CO, ID=ID, IH=IH, IW=IW, OD=OD, OH=OH, OW=OW, nq=nq, ks=ks, PDT=PDT, PH=PH, PW=PW, PD=PD, sdi=sdi, shi=shi,

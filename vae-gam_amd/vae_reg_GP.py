@@ -95,10 +95,15 @@ class VAE(nn.Module):
         inducing-point kernel matrix Ku, gp.py:104-107; > 0: Ku + gp_jitter*I on the unit-variance scale, i.e. the
         inducing prior k_var*(Ku + jitter I), factorised by Cholesky -- needed where the inducing grid is dense against the
         length scale and Ku is singular in any precision, e.g. 64 points).  `dp_gain` (data parallel only):
-        'local' = every rank draws the gains of ITS slice of the minibatch from that slice's own B x B gain covariance (cost
-        independent of the number of ranks; same per-volume marginals, hence the same expected loss and gradient, as the global
-        draw), 'global' = the gains of the whole global minibatch are drawn jointly on every rank (bit-for-bit the one-process
-        global-batch step, but O(B_global^2..3) serial work per rank).  `glm_maps` may be a CSV path
+        'global' = the gains of the whole global minibatch are drawn jointly on every rank from the dense Bg x Bg gain covariance
+        (vae_reg_GP.py:363-369): exactly the one-process global-batch step, but O(Bg^2..3) serial work per rank.
+        'local' = every rank draws the gains of ITS slice from that slice's own B x B block -- the block-DIAGONAL approximation of
+        the joint draw: gains of volumes on different ranks are drawn independently (their covariance through the GP is dropped),
+        every volume's own marginal N(beta_mean_b, Sigma_bb) is unchanged; the HRF of the neural covariates still runs along the
+        GLOBAL batch index across the slices (ops.HrfAcrossRanks).  This is a different stochastic estimate of the loss than the
+        1-rank global-batch step (same expectation for the non-HRF covariates; for an HRF covariate the 14 volumes behind a slice
+        boundary lose the cross-slice covariance terms of their convolved gain); its cost does not grow with the number of ranks.
+        `glm_maps` may be a CSV path
         (reference) or an array of shape (V, C+1) whose column 0 is the CSV index column."""
         super(VAE, self).__init__()
         self.nf, self.save_dir, self.lr = nf, save_dir, lr
@@ -370,12 +375,12 @@ class VAE(nn.Module):
                 'eps_d': torch.randn(B, self.num_latents, device=device, generator=gen),
                 'eps_beta': torch.randn(self.num_covariates, B, device=device, generator=gen)}
 
-    def _gains(self, covariates, eps_beta, join_stream=None):
+    def _gains(self, covariates, eps_beta, join_stream=None, hrf_in_kernel=True):
         """All C gains of a minibatch at once (vae_reg_GP.py:345-378): ONE launch, one workgroup per covariate
         (ops.GpGain -> vg_gp_gain_fwd / _bwd; float64 arithmetic).
         covariates (B, >=C) fp32 -> task_var (C, B) fp32, gp_kl_loss (1,) fp32, beta mean / covariance (float64) and the
         GP posteriors of the continuous covariates ((names, f_bar (K,B), Sigma (K,B,B)) or None)."""
-        K = self._gain_consts(covariates.device)
+        K = self._gain_consts(covariates.device, hrf_in_kernel)
         g32 = self.optimizer.groups[torch.float32]
         params = [p for n in K['names'] for p in self.gp_params[n].values() if isinstance(p, torch.nn.Parameter)]
         tv, kl, bm, bc, fb, sg, kl_terms = ops.GpGain.apply(covariates, eps_beta, K['consts'], g32['p'], g32['g'], join_stream, *params)
@@ -393,10 +398,10 @@ class VAE(nn.Module):
             self._gain_streams[key] = torch.cuda.Stream(device=dev)
         return self._gain_streams[key]
 
-    def _gain_consts(self, dev):
+    def _gain_consts(self, dev, hrf_in_kernel=True):
         """Per device, built once: the table of gain-parameter offsets inside the flat fp32 parameter buffer, the stacked
         inducing grids and the HRF taps (fp32-rounded as the reference's Toeplitz matrix, vae_reg_GP.py:297-299)."""
-        key = str(dev)
+        key = (str(dev), float(self.gp_jitter), int(self.inducing_pts), bool(hrf_in_kernel))   # a changed jitter / grid size builds new constants
         if key not in self._gain_const_cache:
             names = [c.name for c in self.schema]
             g32 = self.optimizer.groups[torch.float32]
@@ -405,10 +410,10 @@ class VAE(nn.Module):
             rows = []
             for i, c in enumerate(self.schema):
                 if c.gp:
-                    rows.append([1, int(c.hrf), gidx.index(i), off['sa_' + c.name], off['logstd_' + c.name], off['qu_m_' + c.name],
+                    rows.append([1, int(c.hrf and hrf_in_kernel), gidx.index(i), off['sa_' + c.name], off['logstd_' + c.name], off['qu_m_' + c.name],
                                  off['qu_S_' + c.name], off['logkvar_' + c.name], off['logls_' + c.name], 0])
                 else:
-                    rows.append([0, int(c.hrf), 0, off['sa_' + c.name], off['logstd_' + c.name], 0, 0, 0, 0, 0])
+                    rows.append([0, int(c.hrf and hrf_in_kernel), 0, off['sa_' + c.name], off['logstd_' + c.name], 0, 0, 0, 0, 0])
             table = torch.tensor(rows, dtype=torch.int64).to(dev)
             xu = torch.stack([self.gp_params[names[i]]['xu'].float() for i in gidx]).contiguous().to(dev) if gidx else None
             hrf = torch.tensor(utils.hrf(np.arange(0, 20, 1.4))).float().double().to(dev) if any(c.hrf for c in self.schema) \
@@ -447,6 +452,11 @@ class VAE(nn.Module):
             noise = self.draw_noise(Bg, dev)
         eps_w, eps_d = noise['eps_w'][lo:lo + B], noise['eps_d'][lo:lo + B]
         eps_beta = noise['eps_beta'] if (joint_gains or W == 1) else noise['eps_beta'][:, lo:lo + B].contiguous()
+        # dp_gain='local': each rank draws the gains of its slice (block-diagonal approximation of the joint B x B gain covariance), but
+        # the HRF still runs along the GLOBAL batch index -- the kernel then leaves the gains un-convolved and ops.HrfAcrossRanks
+        # convolves them across the ranks' slices
+        hrf_rows = [i for i, c in enumerate(self.schema) if c.hrf]
+        hrf_across = W > 1 and not joint_gains and bool(hrf_rows)
         # The gain block (one launch forward, one backward; a single workgroup per covariate walking B serial Cholesky /
         # substitution steps) depends only on the covariates and the gain parameters: it is queued on a second HIP stream
         # beside the encoder/decoder (autograd replays its backward on that stream too, beside the decoder's backward), and
@@ -456,9 +466,9 @@ class VAE(nn.Module):
             main = torch.cuda.current_stream(dev)
             gains_stream.wait_stream(main)
             with torch.cuda.stream(gains_stream):
-                gains = self._gains(covariates, eps_beta, join_stream=main)
+                gains = self._gains(covariates, eps_beta, join_stream=main, hrf_in_kernel=not hrf_across)
         else:
-            gains = self._gains(covariates, eps_beta)
+            gains = self._gains(covariates, eps_beta, hrf_in_kernel=not hrf_across)
         heads = self._encode_heads(x, stacked=True)
         G = C + 1
         # d = exp(a) + 1e-6*[any(d < 1e-6)] (:321-323, no sync), z = rsample (:325), kl_z (:400) and the G decoder
@@ -478,6 +488,9 @@ class VAE(nn.Module):
                 t.record_stream(torch.cuda.current_stream(dev))
         if joint_gains:
             task_var = task_var[:, lo:lo + B].contiguous()                                  # full-batch gains, this rank's columns
+        if hrf_across:
+            conv = ops.HrfAcrossRanks.apply(task_var[hrf_rows], self._hrf_matrix(Bg, dev), self.dp, lo)
+            task_var = torch.cat([conv[hrf_rows.index(i)].unsqueeze(0) if i in hrf_rows else task_var[i:i + 1] for i in range(C)], 0)
         xf = x.reshape(B, self.img_dim)
         slp, dist = ops.GamElbo.apply(logits, task_var, xf, self.epsilon.view(-1), self._glm(), self.convt5.bias)
         # glm_reg = Bg * sum(dist) (:388-389, cdist's factor = global batch); elbo = sum(-kl_z + slp) / Bg (:406-408);
@@ -687,6 +700,8 @@ class VAE(nn.Module):
         state['glm_reg_scale'] = self.glm_reg_scale
         state['gp_kl_scale'] = self.gp_kl_scale
         state['inducing_pts'] = self.inducing_pts
+        if self.gp_jitter:                                # extra key, only when the extension is in use (the reference's loader ignores it):
+            state['gp_jitter'] = self.gp_jitter          # the posterior that was trained is the one a resumed run / the export evaluates
         gp_out = {}
         for cov, d in self.gp_params.items():
             gp_out[cov] = {k: (torch.nn.Parameter(v.detach().clone()) if isinstance(v, torch.nn.Parameter) else v.clone())
@@ -718,6 +733,12 @@ class VAE(nn.Module):
         self.gp_kl_scale = torch.as_tensor(checkpoint['gp_kl_scale']).to(self.device)
         self._gp_kl_scale_host = float(torch.as_tensor(checkpoint['gp_kl_scale']).cpu())
         self.inducing_pts = checkpoint['inducing_pts']
+        self.gp_jitter = float(checkpoint.get('gp_jitter', self.gp_jitter))     # absent in checkpoints of the reference
+        # constants derived from the state just replaced (stacked copies of the inducing grids, jitter) and the hipGraphs that
+        # captured them must not survive the load
+        self._gain_const_cache.clear()
+        self._graphs.clear()
+        self._glm_f32 = None
 
     # ------------------------------------------------------------------ post-hoc (reconstruction export lives in build_model_recons)
     def reconstruct(self, loader, ref_niis, save_dirs, write_volumes=True, noise=None):
@@ -793,7 +814,7 @@ class VAE(nn.Module):
             ls = 3.0 * torch.sigmoid(torch.stack([self.gp_params[n]['log_ls'] for n in names]).to(f64).exp() + 0.5)
             qu_m = torch.cat([self.gp_params[n]['qu_m'] for n in names]).to(f64)
             qu_S = torch.stack([self.gp_params[n]['qu_S'] for n in names]).to(f64)
-            f_bar, var = gp.posterior_diag_batched(xu, kvar, ls, qu_m, qu_S, xq)
+            f_bar, var = gp.posterior_diag_batched(xu, kvar, ls, qu_m, qu_S, xq, jitter=self.gp_jitter)
             sa = torch.cat([self.gp_params[n]['sa'][0] for n in names]).to(f64).unsqueeze(1)
             std = torch.cat([self.gp_params[n]['logstd'][0] for n in names]).to(f64).exp().unsqueeze(1)
             mean = (sa * xq + f_bar).cpu().numpy()
