@@ -117,7 +117,7 @@ def main():
     ap.add_argument('--covariates', type=int, default=8, help='configs[2]: 8 (full model); configs[1]: 3')
     ap.add_argument('--subjects', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-steps', type=int, default=2, help='timed CPU-oracle steps (after 1 warm-up); ~7 s each at batch 64 / 8 covariates on 16 threads')
+    ap.add_argument('--cpu-steps', type=int, default=5, help='timed CPU-oracle steps (median; after 2 warm-ups, SURVEY 8d); ~5 s each at batch 64 / 8 covariates on 16 threads')
     ap.add_argument('--eager', action='store_true', help='launch kernels eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel HIP-event table to stderr')
     a = ap.parse_args()
@@ -256,7 +256,8 @@ def main():
         smp = batches[0]
         xc, cc = smp['volume'].cpu(), smp['covariates'].cpu()
         gen = torch.Generator().manual_seed(0)
-        O.train_step(params, opt, cfg, xc, cc, glm, O.draw_noise(B, cfg, gen))          # warm-up
+        for _ in range(2):                                           # warm-ups (median of >= 5 after 2)
+            O.train_step(params, opt, cfg, xc, cc, glm, O.draw_noise(B, cfg, gen))
         ts, out_last = [], None
         for _ in range(max(1, a.cpu_steps)):
             t1 = time.perf_counter()
@@ -268,7 +269,7 @@ def main():
         t_log = as_shipped.time_forward_logging(out_last, cc, cfg)
         cpu = {'value': round(B / med, 2), 'unit': 'volumes/s', 'cores': nthr, 'kind': 'port',
                'as_shipped_value': round(B / (med + t_log), 2),
-               'sample': '%d train step(s) of batch %d, %d covariates after 1 warm-up (same synthetic minibatch), median, PyTorch CPU '
+               'sample': '%d train step(s) of batch %d, %d covariates after 2 warm-ups (same synthetic minibatch), median, PyTorch CPU '
                          'fp32, compute only; as_shipped_value adds the %.2f s of per-forward logging + host copies the reference '
                          'performs in training (emulated once on the same outputs); %s' % (len(ts), B, C, t_log, thr_note)}
 
@@ -284,7 +285,10 @@ def main():
                                  'continuous covariates, HRF on task, GLM regulariser on; gain / GP algebra on device in fp64'
                                  % ('2' if (B, C) == (64, 8) else '1' if (B, C) == (32, 3) else '-'),
                        'global_batch': B * world, 'covariates': C, 'parallelism': 'dp%d' % world,
-                       **({'dp': 'batch-norm statistics and loss normalisation over the global minibatch (all-reduced), one gradient all-reduce, gains drawn per rank from its own slice (dp_gain=%s)' % model.dp_gain} if world > 1 else {})},
+                       **({'dp': ('batch-norm statistics and loss normalisation over the global minibatch (all-reduced), one gradient all-reduce; dp_gain=%s: ' % model.dp_gain) +
+                                ('gains drawn per rank from its own slice (block-diagonal approximation of the joint B x B gain draw; the HRF runs along the global batch '
+                                 'across ranks) -- NOT the 1-rank global-batch computation, which dp_gain=global reproduces at O(B_global^2..3) serial cost per rank'
+                                 if model.dp_gain == 'local' else 'joint gain draw of the global minibatch on every rank = the 1-rank global-batch step')} if world > 1 else {})},
             'roofline': roofline,
             'step_roofline': {'hbm_frac': round(value / world * ALG_BYTES_PER_VOL.get(C, 0) / (HBM_PEAK_GBS * 1e9), 4),
                               'fp32_frac': round(value / world * ALG_GFLOP_PER_VOL.get(C, 0) / (FP32_PEAK_TF * 1e3), 4),

@@ -350,9 +350,11 @@ def run_gain_case(dev, B=12, n=6, jitter=0.0, seed=0, kinds=('lin_hrf', 'gp', 'g
         for nm in names:
             want = q[nm].grad.reshape(-1)
             have = got[offs[nm]:offs[nm] + want.numel()]
-            # d log_ls / d logkvar are cancelling sums: tiny values carry the fp32-distance noise
+            # d log_ls / d logkvar are cancelling sums: tiny values carry the fp32-distance noise -- one rounding (1e-7 relative, times
+            # cond(Ku)) per query point, so the floor grows with the batch: measured 7e-6 absolute on a 5e-3 gradient at B = 256
             scale = max(float(want.abs().max()), 1e-2)
-            np.testing.assert_allclose(have.numpy(), want.numpy(), rtol=2e-4, atol=2e-4 * scale, err_msg='cov %d (%s) d%s' % (i, kind, nm))
+            grow = max(1.0, B / 32.0) if nm in ('logkvar', 'log_ls') else 1.0
+            np.testing.assert_allclose(have.numpy(), want.numpy(), rtol=2e-4, atol=2e-4 * scale * grow, err_msg='cov %d (%s) d%s' % (i, kind, nm))
 
 
 def _posterior_unit_variance(xu, k_var, ls, qu_m, qu_S, xq, jitter):

@@ -2,6 +2,7 @@
 optimizer state format, CLI flags, data classes, synthetic generator, HRF kernel."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -403,3 +404,49 @@ def test_shard_loaders_rebuilds_every_loader_on_its_dataset(small_ds, tmp_path):
         assert out[k].dataset is loaders[k].dataset
     b = next(iter(out['UnShuffled_train']))
     assert b['volume'].shape[0] == 2 and [int(v) for v in b['vol_num']] == [2, 3]      # rows 2,3 of the first global batch of 4
+
+
+def test_real_data_input_path_matches_the_reference_scripts(tmp_path):
+    """SURVEY 8f-3 against the reference's own arithmetic: tests/golden/preproc_ref.npz holds what `get_beta_map_regularizer.py`
+    (:73-107: FSL design matrices -> OLS beta maps -> max-scaled CSV) and `pre_proc_vaefmri.py` (:97-129: per-volume CSV, z-scored
+    motion) WROTE when oracle/gen_preproc_golden.py ran them in the build container on a seeded synthetic fmriprep / FSL tree.  The
+    same recipe rebuilds the inputs here; utils.read_design_mat / glm_design_columns / glm_beta_maps / preproc_table must reproduce
+    the files: values to 1e-10, column names, index column and row order exactly."""
+    import pandas as pd
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import gen_preproc_golden as P                                        # the recipe and the design.mat writer only
+    from vae_gam_amd import utils
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'preproc_ref.npz'))
+    rc = P.recipe(int(g['seed']))
+    order = list(dict.fromkeys(str(s) for s in g['csv.subjid']))         # the directory order the scripts happened to walk
+    assert sorted(order) == sorted(P.SUBJECTS)
+    # ---- GLM maps
+    designs, datas = [], []
+    for s in order:
+        path = str(tmp_path / (s + '_design.mat'))
+        P.write_design_mat(path, rc[s]['design'])
+        m = utils.read_design_mat(path)
+        np.testing.assert_allclose(m, rc[s]['design'], rtol=0, atol=5e-7)        # %e text round trip
+        designs.append(utils.glm_design_columns(m))
+        datas.append(rc[s]['data'].reshape(-1, P.DIMS[3]))
+    maps = utils.glm_beta_maps(np.concatenate(designs, 0), np.concatenate(datas, 1), sex_map=rc['sex_map'])
+    assert list(g['glm.columns'][1:]) == ['task', 'x', 'y', 'z', 'xrot', 'yrot', 'zrot', 'sex']
+    np.testing.assert_array_equal(g['glm.index'], np.arange(maps.shape[1]))
+    np.testing.assert_allclose(maps.T, g['glm.values'], rtol=1e-10, atol=1e-12)
+    glm_csv = str(tmp_path / 'glm.csv')
+    pd.DataFrame(maps.T, columns=['task', 'x', 'y', 'z', 'xrot', 'yrot', 'zrot', 'sex']).to_csv(glm_csv)
+    assert list(pd.read_csv(glm_csv).columns) == list(g['glm.columns'])
+    # ---- per-volume CSV
+    df = utils.preproc_table([dict(subjid=s, nii_path=s + '_preproc_bold_brainmasked_resampled.nii.gz', motion=rc[s]['motion'], sex=rc[s]['sex'])
+                              for s in order], control=True)
+    csv = str(tmp_path / 'pre.csv')
+    df.to_csv(csv)
+    back = pd.read_csv(csv)
+    assert list(back.columns) == list(g['csv.columns'])
+    np.testing.assert_array_equal(back.iloc[:, 0].to_numpy(), g['csv.index'])
+    assert list(back['subjid']) == [str(s) for s in g['csv.subjid']]
+    np.testing.assert_array_equal(back['volume #'].to_numpy(), g['csv.volume'])
+    assert list(back['nii_path']) == [str(s) for s in g['csv.nii_name']]
+    np.testing.assert_allclose(back[['task', 'x', 'y', 'z', 'rot_x', 'rot_y', 'rot_z', 'sex']].to_numpy(np.float64), g['csv.values'], rtol=1e-10, atol=1e-12)
+    # what the data loader and the model then read from these two files
+    assert len(utils.get_xu_ranges([csv, csv])) == 6

@@ -101,9 +101,9 @@ def test_cholesky(n):
     K.run_cholesky_case('cuda', batch=3, n=n)
 
 
-@pytest.mark.parametrize('B,n,jitter', [(12, 6, 0.0), (64, 6, 0.0), (32, 64, 1e-4), (160, 6, 0.0)])
+@pytest.mark.parametrize('B,n,jitter', [(12, 6, 0.0), (64, 6, 0.0), (32, 64, 1e-4), (160, 6, 0.0), (256, 6, 0.0)])
 def test_gain_block_matches_float64_oracle(B, n, jitter):
-    """vg_gp_gain_fwd / _bwd on the MI355X: B = 64 is bench.py's configs[2] batch (B x B matrix in LDS), B = 160 takes the
-    workspace path of data-parallel global batches (> 128), n = 64 with jitter is configs[4]'s inducing grid
+    """vg_gp_gain_fwd / _bwd on the MI355X: B = 64 is bench.py's configs[2] batch (B x B matrix in LDS), B = 160 and B = 256 (configs[3]'s global
+    minibatch: 8 GPUs x 32) take the workspace path of data-parallel global batches (> 128), n = 64 with jitter is configs[4]'s inducing grid
     (jitter 1e-4: the gradient through Ku^-1 carries cond(Ku)^2 * eps -- at 1e-6, cond ~ 6e7, not even float64 resolves d/d ls)."""
     K.run_gain_case('cuda', B=B, n=n, jitter=jitter, seed=B)

@@ -438,6 +438,74 @@ def test_data_parallel_two_ranks_on_gpu_equal_global_batch(tmp_path):
         assert float((o['g'] - ref_g).norm()) <= 5e-4 * float(ref_g.norm()), (float((o['g'] - ref_g).norm()), float(ref_g.norm()))
 
 
+def _cfg3_rank(rank, world, port, out_dir, dp_gain):
+    import os
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    from vae_gam_amd import dp as dpmod, synthetic
+    ctx = dpmod.DataParallelContext.from_env(backend='gloo')          # one GPU on this box: collectives staged through the host
+    ds = synthetic.make_dataset(num_subjects=2, vols_per_subject=32, num_covariates=8, seed=6)
+    torch.manual_seed(1)
+    model = VAE(num_covariates=8, glm_maps=ds['glm'], xu_ranges=ds['xu_ranges'], device_name='cuda', data_parallel=ctx, dp_gain=dp_gain)
+    b = 32
+    x = torch.from_numpy(ds['volumes'][rank * b:(rank + 1) * b]).cuda(); cov = torch.from_numpy(ds['covariates'][rank * b:(rank + 1) * b]).cuda()
+    model.optimizer.zero_grad()
+    res = model.forward_core(cov, x)                                   # noise: the generator every rank seeds identically
+    res['loss'].backward()
+    from vae_gam_amd import ops
+    ops.join_side_stream(x.device)
+    ctx.allreduce_grads(model.optimizer.flat_grads())
+    g32 = model.optimizer.groups[torch.float32]
+    torch.save({'loss': float(ctx.sum_scalar_tensor(res['loss'].detach())), 'g': g32['g'].cpu(), 'task_var': res['task_var'].detach().cpu()},
+               os.path.join(out_dir, 'rank%d.pt' % rank))
+    ctx.shutdown()
+
+
+@pytest.mark.parametrize('dp_gain', ['global', 'local'])
+def test_configs3_per_rank_workload_two_ranks(tmp_path, dp_gain):
+    """BASELINE configs[3]'s per-rank workload -- the full model, 8 covariates (HRF on task, 6 GP regressors), 32 volumes per rank --
+    under a data-parallel context: 2 ranks on this box's GPU (gloo) against ONE process on the 64-volume global minibatch.
+    'global': the same loss and gradient as the one-process step (joint gain draw on the all-gathered covariates).
+    'local' : the same loss and gradient as the one-process step whose gains are drawn per 32-volume slice (block-diagonal gain
+              covariance) and then convolved with the HRF along all 64 volumes -- the definition of that mode (VAE docstring)."""
+    import socket
+    import torch.multiprocessing as mp
+    from vae_gam_amd import synthetic
+    ds = synthetic.make_dataset(num_subjects=2, vols_per_subject=32, num_covariates=8, seed=6)
+    torch.manual_seed(1)
+    model = VAE(num_covariates=8, glm_maps=ds['glm'], xu_ranges=ds['xu_ranges'], device_name='cuda')
+    Bg, b = 64, 32
+    gen = torch.Generator(device='cuda'); gen.manual_seed(1234)
+    noise = {'eps_w': torch.randn(Bg, 1, device='cuda', generator=gen), 'eps_d': torch.randn(Bg, 32, device='cuda', generator=gen),
+             'eps_beta': torch.randn(8, Bg, device='cuda', generator=gen)}
+    x = torch.from_numpy(ds['volumes'][:Bg]).cuda(); cov = torch.from_numpy(ds['covariates'][:Bg]).cuda()
+    if dp_gain == 'local':
+        orig = model._gains
+        hrf_rows = [i for i, c in enumerate(model.schema) if c.hrf]
+
+        def per_slice_gains(covariates, eps_beta, join_stream=None, hrf_in_kernel=True):
+            outs = [orig(covariates[r * b:(r + 1) * b], eps_beta[:, r * b:(r + 1) * b].contiguous(), join_stream, hrf_in_kernel=False) for r in range(2)]
+            tv = torch.cat([o[0] for o in outs], 1)
+            tv = torch.cat([model.do_hrf_conv(tv[i]).unsqueeze(0) if i in hrf_rows else tv[i:i + 1] for i in range(tv.shape[0])], 0)
+            return (tv, outs[0][1]) + tuple(outs[0][2:])
+        model._gains = per_slice_gains
+        model.overlap_gains = False
+    model.optimizer.zero_grad()
+    res = model.forward_core(cov, x, noise)
+    res['loss'].backward()
+    from vae_gam_amd import ops
+    ops.join_side_stream(x.device)
+    ref_loss = float(res['loss']); ref_g = model.optimizer.groups[torch.float32]['g'].cpu(); ref_tv = res['task_var'].detach().cpu()
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_cfg3_rank, args=(2, port, str(tmp_path), dp_gain), nprocs=2, join=True)
+    outs = [torch.load(os.path.join(tmp_path, 'rank%d.pt' % r)) for r in range(2)]
+    assert torch.equal(outs[0]['g'], outs[1]['g'])
+    for r, o in enumerate(outs):
+        np.testing.assert_allclose(o['task_var'].numpy(), ref_tv[:, r * b:(r + 1) * b].numpy(), rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(o['loss'], ref_loss, rtol=2e-5)
+        assert float((o['g'] - ref_g).norm()) <= 5e-4 * float(ref_g.norm()), (float((o['g'] - ref_g).norm()), float(ref_g.norm()))
+
+
 def test_reconstruct_writes_reference_layout_and_averages(tmp_path):
     """VAE.reconstruct (vae_reg_GP.py:585-620) + build_model_recons (:15-116) through the HIP path: every
     per-volume file equals the maps of forward(return_latent_rec=True); subject / grand averages equal the means of those files."""

@@ -72,6 +72,55 @@ def glm_beta_maps(design, data, sex_map=None):
     return scale_beta_maps(beta)
 
 
+def read_design_mat(mat_file_path):
+    """FSL feat `design.mat` -> (time points, regressors) array (utils.py:153-168): five header lines, then tab-separated rows."""
+    import re
+    rows = []
+    with open(mat_file_path) as f:
+        for line in f.readlines()[5:]:
+            cells = [c for c in re.split(r'\t+', line.rstrip()) if c != '']
+            if cells:
+                rows.append([float(c) for c in cells])
+    return np.array(rows)
+
+
+def glm_design_columns(design_mat):
+    """The columns of one subject's FSL design matrix the GLM regulariser uses (get_beta_map_regularizer.py:86-90): the task regressor
+    (first column) and the six motion parameters (last six)."""
+    m = np.asarray(design_mat, dtype=np.float64)
+    return np.concatenate([m[:, :1], m[:, -6:]], axis=1)
+
+
+PREPROC_COLUMNS = ["subjid", "volume #", "nii_path", "task", "x", "y", "z", "rot_x", "rot_y", "rot_z", "sex"]
+
+
+def stimulus_to_neural(vol_times, block=20.0):
+    """Block design of the checkerboard task: OFF first, ON during odd 20-s blocks (utils.py:75-91)."""
+    t = (np.asarray(vol_times) // block).astype(np.int64)
+    return (t % 2 != 0).astype(np.int64)
+
+
+def preproc_table(subjects, control=False, tr=1.4):
+    """The per-volume table `FMRIDataset` reads, as pre_proc_vaefmri.py:97-129 builds it: one row per (subject, volume) with the columns
+    PREPROC_COLUMNS -- task = the block time course at (volume+1)*TR (`control`: the control experiments' ON-first design), the six
+    fmriprep motion regressors, the subject's sex -- and the motion columns z-scored over ALL rows with the population standard
+    deviation (utils.py:113-123).  `subjects`: iterable of dicts {subjid, nii_path, motion (T,6) [trans_x, trans_y, trans_z, rot_x,
+    rot_y, rot_z], sex}.  Returns a pandas DataFrame; `.to_csv(path)` gives the reference's file (index column first)."""
+    import pandas as pd
+    rows = []
+    for s in subjects:
+        mot = np.asarray(s['motion'], dtype=np.float64)
+        T = mot.shape[0]
+        times = np.arange(1, T + 1) * tr
+        neural = control_stimulus_to_neural(times) if control else stimulus_to_neural(times)
+        for v in range(T):
+            rows.append((s['subjid'], v, s['nii_path'], neural[v]) + tuple(mot[v]) + (s['sex'],))
+    df = pd.DataFrame(rows, columns=PREPROC_COLUMNS)
+    cols = ['x', 'y', 'z', 'rot_x', 'rot_y', 'rot_z']
+    df[cols] = zscore_columns(df[cols].to_numpy())
+    return df
+
+
 def log_map(writer, img_shape, maps, slice_idx, tag, batch_size, log_type):
     """Axial slice of every batch element to the writer (subset of utils.py:373-389; opt-in)."""
     add = getattr(writer, 'add_images', None)
