@@ -72,7 +72,8 @@ int vg_tconv3d_s2_stats(const vg_conv_desc* d, const float* x, const float* wpk,
  *   tau   [sum_q ks[q]][4] int32: the window offset dd*IH*IW + dh*IW + dw of (step, kk);  dlt [sum_q ks[q]][4][3] int32: (dd, dh, dw).
  *   position (pd, ph, pw) reads input element (pd*sdi + dd, ph*shi + dh, pw*swi + dw) (zero outside the tensor) and writes output
  *   (pd*sdo + od0[q], ph*sho + oh0[q], pw*swo + ow0[q] + replica).
- *   Block b of a sample stages input planes [b*PD*sdi + d0, + LD) of cc channels at a time (flat LDS-DMA; dbuf: double-buffered).
+ *   Block (bd, bh) of a sample works on position planes [bd*PD, +PD) x rows [bh*PHB, +PHB) and stages, cc channels at a time, the rows
+ *   [bh*PHB*shi + hlo, ...+ (PHB-1)*shi + hhi] of input planes [bd*PD*sdi + d0, + LD) (LDS-DMA, one contiguous span per plane; dbuf: double-buffered).
  * bias / in_scale / in_shift / mask_src / stats_*: as vg_corr3d / vg_tconv3d_s2_stats (stats chunks: vg_conv_mm_stats_chunks). */
 typedef struct vg_mm_desc {
     int32_t N, CI, CO;
@@ -83,6 +84,9 @@ typedef struct vg_mm_desc {
     int32_t sdo, sho, swo, od0[4], oh0[4], ow0[4];
     int32_t relu_in, per_group, tpc, slack;
     int32_t dbuf;              /* 1: input planes double-buffered (copy of unit u+1 behind unit u's matrix work); 0: single buffer, half the LDS */
+    int32_t PHB;               /* position rows per block (a block = PD planes x PHB rows x PW columns); 0 or >= PH: whole planes */
+    int32_t hlo, hhi;          /* smallest / largest row offset dh in the window-offset table: which input rows a row slab stages */
+    int32_t waves;             /* wavefronts per workgroup: 8 or 4 (4: half the tile, twice the co-resident workgroups per CU) */
 } vg_mm_desc;
 int64_t vg_conv_mm_stats_chunks(const vg_mm_desc* d, int32_t stats_per_group);
 int vg_conv_mm(const vg_mm_desc* d, const float* x, const float* a_img, const int32_t* tau, const int32_t* dlt, const float* bias,

@@ -44,22 +44,27 @@ for item in sys.argv[3:]:
         ref = ops.conv_mm(x, base, aimg0, b, True, sc, sh, B, None, None)
     else:
         ref = ops.conv_mm(dy, base, aimg0, None, False, None, None, 1, x)
-    for PD in range(1, 9):
-        for cc in [c for c in range(ci, 0, -1) if ci % c == 0]:
-          for dbuf in (1, 0):
-            pl = ops.mm_plan(sp, direction, sizes[i] if direction == 'fwd' else sizes[i + 1], None if direction == 'fwd' else sizes[i], force=(PD, cc, dbuf))
-            if pl is None:
-                continue
-            aimg = pl.gather(w)
-            if direction == 'fwd':
-                fn = lambda: ops.conv_mm(x, pl, aimg, b, True, sc, sh, B, None, None)
-            else:
-                fn = lambda: ops.conv_mm(dy, pl, aimg, None, False, None, None, 1, x)
-            try:
-                out = fn()
-                err = float((out - ref).abs().max())
-                t = timeit(fn)
-            except Exception as e:
-                print('  PD %d cc %d db %d: %s' % (PD, cc, dbuf, str(e)[:80])); continue
-            lds = pl.aidx.size * 4 + sum(pl.ks) * 256 + (1 + dbuf) * cc * (64 + ((pl.LD * pl.IH * pl.IW + 63) // 64) * 64) * 4 + 256
-            print('  PD %d cc %2d db %d tpc %d LD %2d lds %6d  %8.1f us   maxdiff %.2e' % (PD, cc, dbuf, pl.tpc, pl.LD, lds, t, err), flush=True)
+    shi = base.shi
+    for W in (8, 4):
+      for PD in range(1, 9):
+        for nslab in (1, 2, 3, 4, 6):
+          PHB = (base.PH + nslab - 1) // nslab
+          if nslab > 1 and (base.PH + PHB - 1) // PHB != nslab:
+              continue
+          for cc in [c for c in range(ci, 0, -1) if ci % c == 0][:3]:
+            for dbuf in (0, 1):
+                pl = ops.mm_plan(sp, direction, sizes[i] if direction == 'fwd' else sizes[i + 1], None if direction == 'fwd' else sizes[i], force=(W, PD, PHB, cc, dbuf))
+                if pl is None:
+                    continue
+                aimg = pl.gather(w)
+                if direction == 'fwd':
+                    fn = lambda: ops.conv_mm(x, pl, aimg, b, True, sc, sh, B, None, None)
+                else:
+                    fn = lambda: ops.conv_mm(dy, pl, aimg, None, False, None, None, 1, x)
+                try:
+                    out = fn()
+                    err = float((out - ref).abs().max())
+                    t = timeit(fn, 5)
+                except Exception as e:
+                    print('  W %d PD %d PHB %d cc %d db %d: %s' % (W, PD, PHB, cc, dbuf, str(e)[:80])); continue
+                print('  W %d PD %d PHB %2d cc %2d db %d tpc %d  %8.1f us   maxdiff %.2e' % (W, PD, PHB, cc, dbuf, pl.tpc, t, err), flush=True)

@@ -45,12 +45,15 @@ for item in which:
     w = torch.randn(wshape, device=dev) * 0.1
     b = torch.zeros(sp.co, device=dev)
     sc = torch.ones((N // B) * sp.ci, device=dev); sh = torch.zeros((N // B) * sp.ci, device=dev)
+    force = tuple(int(v) for v in os.environ['VG_FORCE'].split(',')) if os.environ.get('VG_FORCE') else None
+    if force:
+        pl_ = ops.mm_plan(sp, direction, sizes[i] if direction == 'fwd' else sizes[i + 1], None if direction == 'fwd' else sizes[i], force=force)
     if direction == 'fwd':
-        mm = ops._mm_for(None, w, sp, 'fwd', sizes[i], None)
+        mm = ops._mm_for(None, w, sp, 'fwd', sizes[i], None) if not force else (pl_, pl_.gather(w))
         fn = lambda: ops.conv_mm(x, mm[0], mm[1], b, True, sc, sh, B, None, (B if name in ('convt2', 'convt4') and not os.environ.get('VG_NOSTATS') else None))
     else:
         dy = torch.randn((N, sp.co) + sizes[i + 1], device=dev)
-        mm = ops._mm_for(None, w, sp, 'bwd', sizes[i + 1], sizes[i])
+        mm = ops._mm_for(None, w, sp, 'bwd', sizes[i + 1], sizes[i]) if not force else (pl_, pl_.gather(w))
         fn = lambda: ops.conv_mm(dy, mm[0], mm[1], None, False, None, None, 1, x)
     if mm is None:
         print(item, 'no plan'); continue

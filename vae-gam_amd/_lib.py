@@ -31,7 +31,7 @@ class WgradDesc(ctypes.Structure):
 class MmDesc(ctypes.Structure):
     _fields_ = [(n, i32) for n in ('N', 'CI', 'CO', 'ID', 'IH', 'IW', 'OD', 'OH', 'OW', 'nq')] + [('ks', i32 * 4)] + \
                [(n, i32) for n in ('PDT', 'PH', 'PW', 'PD', 'sdi', 'shi', 'swi', 'd0', 'LD', 'cc', 'sdo', 'sho', 'swo')] + \
-               [('od0', i32 * 4), ('oh0', i32 * 4), ('ow0', i32 * 4)] + [(n, i32) for n in ('relu_in', 'per_group', 'tpc', 'slack', 'dbuf')]
+               [('od0', i32 * 4), ('oh0', i32 * 4), ('ow0', i32 * 4)] + [(n, i32) for n in ('relu_in', 'per_group', 'tpc', 'slack', 'dbuf', 'PHB', 'hlo', 'hhi', 'waves')]
 
 
 class GainDesc(ctypes.Structure):

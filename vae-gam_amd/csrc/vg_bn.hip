@@ -325,8 +325,7 @@ bn_tconv1_k(const float* __restrict__ dy, const float* __restrict__ w, const flo
     {
         const float* src = dy + ((size_t)n * (a.ID + 2) + d0) * oplane;
         const int nfl = (nd + 2) * oplane;
-        for (int o = wave * VG_WAVE; o < nfl; o += BN_THREADS)
-            if (o + lane < nfl) vg_dma4(src + o + lane, tile + o);
+        vg_dma_block(src, tile, nfl, wave, BN_THREADS / VG_WAVE, lane);
         vg_dma_wait();
     }
     __syncthreads();

@@ -109,6 +109,32 @@ __device__ __forceinline__ void vg_dma_span16(const float* src_lane, float* dst,
 }
 #endif
 
+// n contiguous floats, global -> LDS, by the `nw` waves of a block together (nw = 1, wave = 0: by one wave alone).  The source needs
+// only 4-byte alignment (measured: tools/micro/dma16_align.hip -- global_load_lds_dwordx4 takes any dword-aligned address), so
+// everything from the first 16-byte boundary of the LDS destination on moves as 1 KB wave-instructions (a quarter of the
+// instructions of the dword form, whose issue was 5-25 % of a wave's cycles in the conv / weight-gradient kernels); the up to 3 floats
+// in front of that boundary and behind the last whole 16 bytes go as dword copies.  Wave w takes the whole 1 KB pieces w, w + nw, ...
+#ifdef VG_EMU
+static inline void vg_dma_block(const float* src, float* dst, int n, int wave, int nw, int lane) {
+    for (int i = wave * 64 + lane; i < n; i += nw * 64) dst[i] = src[i];
+}
+#else
+__device__ __forceinline__ void vg_dma_block(const float* src, float* dst, int n, int wave, int nw, int lane) {
+    int h = (int)((4u - (((unsigned)(uintptr_t)dst >> 2) & 3u)) & 3u);
+    if (h > n) h = n;
+    if (wave == 0 && lane < h) vg_dma4(src + lane, dst);
+    const int nb = (n - h) >> 8;
+    const float* s_ = src + h + 4 * lane; float* d_ = dst + h;
+    for (int k = wave; k < nb; k += nw) vg_dma16(s_ + (k << 8), d_ + (k << 8));
+    if (wave == nb % nw) {
+        const int r0 = h + (nb << 8), r4 = (n - r0) >> 2;
+        if (lane < r4) vg_dma16(src + r0 + 4 * lane, dst + r0);
+        const int t0 = r0 + (r4 << 2);
+        if (lane < n - t0) vg_dma4(src + t0 + lane, dst + t0);
+    }
+}
+#endif
+
 // Wait until at most n (wave-uniform, a multiple of 4 up to 32) of this wave's vector-memory operations are outstanding: they retire in
 // issue order, so everything issued BEFORE the last n -- e.g. an LDS-DMA copy issued ahead of n stores -- has completed, while the stores
 // keep draining.  n outside the table waits for everything.

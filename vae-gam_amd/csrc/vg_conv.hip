@@ -330,8 +330,7 @@ corr3d_plane_k(const float* __restrict__ x, const float* __restrict__ wpk, const
         for (int c = 0; c < cc; ++c) {
             const float* src = xsrc + (size_t)(c0 + c) * vol;
             float* dst = buf + c * p.ch_floats + dst0;
-            for (int o = wave * VG_WAVE; o < nfl; o += blockDim.x)
-                if (o + lane < nfl) vg_dma4(src + o + lane, dst + o);
+            vg_dma_block(src, dst, nfl, wave, (int)(blockDim.x / VG_WAVE), lane);
         }
     };
     const int buf_floats = p.CCH * p.ch_floats;

@@ -33,9 +33,7 @@ __device__ unsigned long long vg_stamp_out[1024 * 16 * 8];
 
 namespace {
 
-constexpr int MM_T = 512;                  // 8 wavefronts: two per SIMD.  (Measured alternative: 4-wave workgroups, 2-3 per CU, single-buffered
-constexpr int MM_W = MM_T / VG_WAVE;       // input -- twice the tiles per wave, fewer planes per block, more re-staging: 1.3-1.7x slower.)
-constexpr int MM_MAXQ = 4;
+constexpr int MM_MAXQ = 4;                 // (workgroups are MM_W = 8 or 4 wavefronts: a template parameter of the kernel)
 constexpr int MM_ZPAD = 64;                // zero floats at the head of every channel slot: where B operands that do not exist are read from
 
 struct MmParams {
@@ -45,9 +43,9 @@ struct MmParams {
     int kstot, aimg_floats;
     int a_res;                             // 1: the whole A image stays in LDS; 0: the slices of the running channel chunk are staged with it
     int CHP, buf_floats;                   // channel pitch, floats of the input buffer
+    int nhb, PHB, h0, LH, LPH;             // row slabs per plane, position rows per slab, first staged row relative to ph0*shi, staged rows, LDS plane pitch
     int tau_off, in_off;                   // LDS float offsets
     int has_pro;
-    int x4;                                // input spans and tensor base 16-byte aligned: 16-byte LDS-DMA
 };
 
 struct alignas(16) mm_f4 { float v[4]; };   // one ds_read_b128 / ds_write_b128
@@ -81,13 +79,14 @@ __device__ __forceinline__ void mm_static_for(F&& f) {
 // bits set up once per block, stores through a uniform base + 32-bit lane offset, and -- data gradients -- fetches the ReLU mask
 // of a sample BEFORE that sample's last matrix phase instead of between its stores (that wait was 48 % of convt3's data gradient);
 // (iv) a wave copies AND post-processes whole channel spans (16-byte LDS accesses), statistics are flushed per group run.
-template <int NQ, int TPC, int K0, int K1, int K2, int K3, bool DB, int OCC, bool MASKED>
-__global__ void __launch_bounds__(MM_T, OCC)
+template <int MM_W, int NQ, int TPC, int K0, int K1, int K2, int K3, bool DB, int OCC, bool MASKED>
+__global__ void __launch_bounds__(MM_W * VG_WAVE, OCC)
 conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const int* __restrict__ tau, const int* __restrict__ dlt,
           const float* __restrict__ bias, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
           const float* __restrict__ mask_src, float* __restrict__ y, double* __restrict__ stats_part, int stats_pg, int stats_relu,
           MmParams p) {
     VG_DYN_SMEM(float, lds);
+    constexpr int MM_T = MM_W * VG_WAVE;
     const vg_mm_desc& d = p.d;
     float* Al = lds;
     int* Tl = reinterpret_cast<int*>(lds + p.tau_off);
@@ -102,18 +101,34 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
     constexpr int KSUM = K0 + K1 + K2 + K3;
 
     for (int i = tid; i < p.aimg_floats; i += MM_T) Al[i] = a_img[i];
-    if (!STATIC_K) for (int i = tid; i < p.kstot * 64; i += MM_T) Tl[i] = tau[(i >> 6) * 4 + ((i & 63) >> 4)];
+    if (!STATIC_K) for (int i = tid; i < p.kstot * 64; i += MM_T) {
+        const int* e = dlt + ((i >> 6) * 4 + ((i & 63) >> 4)) * 3;
+        Tl[i] = e[0] * p.LPH + e[1] * d.IW + e[2];
+    }
     for (int i = tid; i < (DB ? 2 : 1) * d.cc * MM_ZPAD; i += MM_T) In[(i / MM_ZPAD) * p.CHP + (i % MM_ZPAD)] = 0.f;  // the zero pads (never written again)
 
-    // ---- geometry of this block (the same for every sample it visits)
-    const int pd0 = b * d.PD;
-    const int npd = min(d.PD, d.PDT - pd0);
-    const int npos = npd * d.PH * d.PW;
+    // ---- geometry of this block (the same for every sample it visits): slab b = (plane slab bd, row slab bh) of the position grid
+    const int bd = b / p.nhb, bh = b - bd * p.nhb;
+    const int pd0 = bd * d.PD, ph0 = bh * p.PHB;
+    const int npd = min(d.PD, d.PDT - pd0), nph = min(p.PHB, d.PH - ph0);
+    const int npos = npd * nph * d.PW;
     const int ntiles = (npos + 15) / 16;
     const int dlo = pd0 * d.sdi + d.d0;                                  // first staged input plane (may lie outside the tensor)
     const int pl_lo = max(dlo, 0), pl_hi = min(dlo + d.LD, d.ID);
-    const int nfl = max(pl_hi - pl_lo, 0) * IHW;                         // floats to copy per channel
-    const int dst0 = (pl_lo - dlo) * IHW;
+    const int npl = max(pl_hi - pl_lo, 0);
+    const int rlo = ph0 * d.shi + p.h0;                                  // first staged input row of every plane (may lie outside it)
+    const int r_lo = max(rlo, 0), r_hi = min(rlo + p.LH, d.IH);
+    const int LPH = p.LPH;
+    // staged rows of a plane are one contiguous span; if they are ALL rows of the plane and the LDS plane pitch is the tensor's, the
+    // planes of a channel are one span as well
+    const bool flat = (r_lo == 0 && r_hi == d.IH && LPH == IHW);
+    const int span_fl = flat ? npl * IHW : max(r_hi - r_lo, 0) * d.IW;   // floats per span
+    const int nspan_c = flat ? 1 : npl;                                  // spans per channel
+    // LDS float offset (past the zero pad) of the first staged element.  A plane's slot begins with its first STAGED row (r_lo: rows
+    // outside the tensor take no space -- their operands point at the zero pad) and LPH is a multiple of 4 (host), so every span starts
+    // on a 16-byte boundary; a span's last 16-byte group may reach up to 3 floats past its end -- into the slack the host leaves
+    // behind every plane (LPH >= rows*IW + 4), never into another span
+    const int dst0 = (pl_lo - dlo) * LPH;
     const size_t vol = (size_t)IHW * d.ID, ovol = (size_t)OHW * d.OD;
     // rows 4*kk .. 4*kk+3 of a tile: replica and first channel are lane constants
     const int rho_l = (CO == 8) ? (kk >> 1) : 0;
@@ -133,8 +148,9 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
         const int pf = (i * MM_W + wave) * 16 + jl;
         const bool pv = pf < npos;
         const int pfc = pv ? pf : 0;
-        const int pdl = pfc / (d.PH * d.PW), r2 = pfc - pdl * (d.PH * d.PW);
-        const int ph = r2 / d.PW, pw = r2 - ph * d.PW;
+        const int pdl = pfc / (nph * d.PW), r2 = pfc - pdl * (nph * d.PW);
+        const int phl = r2 / d.PW, pw = r2 - phl * d.PW;
+        const int ph = ph0 + phl;
         const int obd = (pd0 + pdl) * d.sdo, obh = ph * d.sho, obw = pw * d.swo + rho_l;
         ob[i] = obd * OHW + obh * d.OW + obw + co_l * (int)ovol;
 #pragma unroll
@@ -143,7 +159,7 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
             const bool ok = pv && od >= 0 && od < d.OD && oh >= 0 && oh < d.OH && ow >= 0 && ow < d.OW;
             vbits |= (ok ? 1u : 0u) << (q * TPC + i);
         }
-        const int pb = (pdl * d.sdi - d.d0) * IHW + ph * d.shi * d.IW + pw * d.swi;
+        const int pb = (pdl * d.sdi - d.d0) * LPH + (ph * d.shi - r_lo) * d.IW + pw * d.swi;
         posBase[i] = pb;
         if constexpr (STATIC_K) {
 #pragma unroll
@@ -151,7 +167,7 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
                 const int* e = dlt + (sg * 4 + kk) * 3;
                 const int id = (pd0 + pdl) * d.sdi + e[0], ih = ph * d.shi + e[1], iw = pw * d.swi + e[2];
                 const bool ok = pv && id >= 0 && id < d.ID && ih >= 0 && ih < d.IH && iw >= 0 && iw < d.IW;
-                pt[i][sg] = ok ? MM_ZPAD + pb + tau[sg * 4 + kk] : 0;
+                pt[i][sg] = ok ? MM_ZPAD + pb + e[0] * LPH + e[1] * d.IW + e[2] : 0;      // (the host's tau assumes whole planes)
             }
         } else {
 #pragma unroll
@@ -264,26 +280,29 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
         }
     };
 
-    // Input planes of unit u (sample, channel chunk): one contiguous span per channel, flat LDS-DMA.  The span of a channel is cut into
-    // `parts` pieces of whole 16-byte groups and every (channel, piece) belongs to ONE wave, which copies it and -- after its own
-    // vmcnt(0) -- applies the producer's ReLU / batch-norm affine to it in place: no barrier between copy and prologue.
-    const int parts = (d.cc >= MM_W) ? 1 : MM_W / d.cc;
-    const int head = dst0 & 3;                                           // the span starts `head` floats past a 16-byte boundary of its slot
-    const int n4 = (head + nfl + 3) >> 2;                                // 16-byte groups that cover it
+    // Input of unit u (sample, channel chunk): per channel the staged rows of every staged plane -- one contiguous span per plane, or one
+    // per channel where whole planes at the tensor's own pitch are staged (`flat`) -- by LDS-DMA.  A span is cut into `parts` pieces of
+    // whole 16-byte groups and every (channel, span, piece) belongs to ONE wave, which copies it and -- after its own vmcnt wait --
+    // applies the producer's ReLU / batch-norm affine to it in place: no barrier between copy and prologue.
+    const int nsp = d.cc * nspan_c;
+    const int parts = (nsp >= MM_W) ? 1 : (MM_W + nsp - 1) / nsp;
+    // non-flat: every span starts on a 16-byte boundary (above).  flat (tensor pitch, one span per channel): it starts `head` floats past
+    // one; the floats of its first / last 16-byte group outside the span lie inside the channel slot, past the zero pad, and no operand
+    // offset points at them
+    const int head = dst0 & 3;
+    const int n4 = (head + span_fl + 3) >> 2;                            // 16-byte groups that cover a span
     const int n4p = (n4 + parts - 1) / parts;
     auto stage = [&](int u) __attribute__((always_inline)) {
         const int n = split + (u / nchunks) * p.nsplit, c0 = (u % nchunks) * d.cc;
         const int cc = min(d.cc, CI - c0);
         float* buf = In + (DB ? (u & 1) : 0) * p.buf_floats;
-        const float* src0 = x + ((size_t)n * CI + c0) * vol + (size_t)pl_lo * IHW;
-        for (int it = wave; it < cc * parts; it += MM_W) {
-            const int c = it / parts, part = it - c * parts;
+        const float* src0 = x + ((size_t)n * CI + c0) * vol + (size_t)pl_lo * IHW + (size_t)r_lo * d.IW;
+        for (int it = wave; it < cc * nspan_c * parts; it += MM_W) {
+            const int sp = it / parts, part = it - sp * parts;
+            const int c = sp / nspan_c, pl = sp - c * nspan_c;
             const int g0 = part * n4p, g1 = min(g0 + n4p, n4);
-            const int f0 = max(g0 * 4 - head, 0), f1 = min(g1 * 4 - head, nfl);    // floats [f0, f1) of the span
-            if (f1 > f0) {
-                if (p.x4) vg_dma_span16(src0 + (size_t)c * vol + f0 + 4 * lane, buf + c * p.CHP + MM_ZPAD + dst0 + f0, f1 - f0, lane);
-                else vg_dma_span(src0 + (size_t)c * vol + f0 + lane, buf + c * p.CHP + MM_ZPAD + dst0 + f0, f1 - f0, lane);
-            }
+            const int f0 = max(g0 * 4 - head, 0), f1 = min(g1 * 4 - head, span_fl);     // floats [f0, f1) of the span
+            if (f1 > f0) vg_dma_block(src0 + (size_t)c * vol + (size_t)pl * IHW + f0, buf + c * p.CHP + MM_ZPAD + dst0 + pl * LPH + f0, f1 - f0, 0, 1, lane);
         }
     };
     auto prologue = [&](int u) __attribute__((always_inline)) {
@@ -291,25 +310,24 @@ conv_mm_k(const float* __restrict__ x, const float* __restrict__ a_img, const in
         const int cc = min(d.cc, CI - c0);
         float* buf = In + (DB ? (u & 1) : 0) * p.buf_floats;
         const int g_aff = (in_scale != nullptr) ? n / d.per_group : 0;
-        for (int it = wave; it < cc * parts; it += MM_W) {
-            const int c = it / parts, part = it - c * parts;
+        for (int it = wave; it < cc * nspan_c * parts; it += MM_W) {
+            const int sp = it / parts, part = it - sp * parts;
+            const int c = sp / nspan_c, pl = sp - c * nspan_c;
             float sc = 1.f, sh = 0.f;
             if (in_scale != nullptr) { sc = in_scale[g_aff * CI + c0 + c]; sh = in_shift[g_aff * CI + c0 + c]; }
-            mm_f4* v4 = reinterpret_cast<mm_f4*>(buf + c * p.CHP + MM_ZPAD + dst0 - head);   // 16-byte aligned: slot bases and dst0 - head are
-            const int g1 = min((part + 1) * n4p, n4);
-            // the first / last group may hold up to 3 floats outside the span: they lie past the zero pad and no operand offset points at them
+            float* sp0 = buf + c * p.CHP + MM_ZPAD + dst0 + pl * LPH - head;    // the 16-byte boundary at / in front of the span's first float
+            const int g0 = part * n4p, g1 = min((part + 1) * n4p, n4);
 #ifdef VG_EMU
-            for (int g = part * n4p + lane; g < g1; g += VG_WAVE) {
-                mm_f4 t = v4[g];
+            for (int g = g0 + lane; g < g1; g += VG_WAVE) {
+                float* t = sp0 + g * 4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) t.v[e] = fmaf(vg_max(t.v[e], lo), sc, sh);
-                v4[g] = t;
+                for (int e = 0; e < 4; ++e) t[e] = fmaf(vg_max(t[e], lo), sc, sh);
             }
 #else
             // LDS accesses as inline asm: in front of a ds_read the compiler can see, its wait-count pass puts s_waitcnt vmcnt(0) while an
             // LDS-DMA is outstanding -- which also waits for every store of the previous unit (the counted wait above exists to avoid that)
-            for (int g = part * n4p + lane; g < g1; g += VG_WAVE) {
-                const unsigned a = (unsigned)(uintptr_t)(v4 + g);
+            for (int g = g0 + lane; g < g1; g += VG_WAVE) {
+                const unsigned a = (unsigned)(uintptr_t)(sp0 + g * 4);
                 vg_hw_f32x4 t;
                 asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(a) : "memory");
 #pragma unroll
@@ -461,7 +479,6 @@ static int mm_plan_params(const vg_mm_desc* d, MmParams* p, size_t* shmem, const
         vg_set_error("%s: bad descriptor", who); return VG_ERR_ARG;
     }
     p->d = *d;
-    p->bps = vg_cdiv(d->PDT, d->PD);
     int ns = 256 / p->bps; if (ns < 1) ns = 1; if (ns > d->N) ns = d->N;
     p->nsplit = ns;
     int row = 0, af = 0;
@@ -473,21 +490,36 @@ static int mm_plan_params(const vg_mm_desc* d, MmParams* p, size_t* shmem, const
     p->kstot = row; p->aimg_floats = af;
     if (d->nq > 1 && d->cc < d->CI) { vg_set_error("%s: multi-class plans need all input channels in one chunk", who); return VG_ERR_ARG; }
     const int IHW = d->IH * d->IW;
-    p->CHP = MM_ZPAD + ((d->LD * IHW + 63) / 64) * 64;                   // [zero pad][LD planes]
+    const int W = d->waves;
+    if (W != 4 && W != 8) { vg_set_error("%s: waves per workgroup must be 4 or 8 (got %d)", who, W); return VG_ERR_ARG; }
+    if (d->hhi < d->hlo) { vg_set_error("%s: bad row-offset range [%d, %d]", who, d->hlo, d->hhi); return VG_ERR_ARG; }
+    // row slabs: PHB position rows per block (0 / >= PH: whole planes); a slab stages the input rows its windows touch
+    p->PHB = (d->PHB > 0 && d->PHB < d->PH) ? d->PHB : d->PH;
+    p->nhb = vg_cdiv(d->PH, p->PHB);
+    p->h0 = d->hlo;
+    p->LH = (p->PHB - 1) * d->shi + (d->hhi - d->hlo) + 1;
+    const int rows_max = p->LH < d->IH ? p->LH : d->IH;                  // rows outside the tensor take no LDS
+    // whole planes keep the tensor's own pitch (one flat copy per channel where every row is staged); row slabs: the staged rows +
+    // slack for the last 16-byte group of a plane's span, planes on 16-byte boundaries
+    const bool whole = p->PHB == d->PH && d->hlo <= 0 && (d->PH - 1) * d->shi + d->hhi + 1 >= d->IH;    // every row of every staged plane: `flat` in the kernel
+    p->LPH = whole ? IHW : ((rows_max * d->IW + 3) / 4) * 4 + 4;
+    p->CHP = MM_ZPAD + ((d->LD * p->LPH + 63) / 64) * 64;                // [zero pad][LD planes]
     p->buf_floats = d->cc * p->CHP;
     p->a_res = 1;
     p->tau_off = ((p->aimg_floats + 63) / 64) * 64;
     p->in_off = p->tau_off + p->kstot * 64;
+    p->bps = vg_cdiv(d->PDT, d->PD) * p->nhb;
     const size_t total = (size_t)p->in_off + (d->dbuf ? 2 : 1) * (size_t)p->buf_floats + 64;
     *shmem = total * sizeof(float);
     if (*shmem > 160 * 1024) { vg_set_error("%s: plan needs %zu bytes of LDS", who, *shmem); return VG_ERR_UNSUPPORTED; }
-    if (d->PD * d->PH * d->PW > d->tpc * MM_W * 16) { vg_set_error("%s: %d positions per block exceed tpc=%d", who, d->PD * d->PH * d->PW, d->tpc); return VG_ERR_ARG; }
+    if (d->PD * p->PHB * d->PW > d->tpc * W * 16) { vg_set_error("%s: %d positions per block exceed tpc=%d x %d waves", who, d->PD * p->PHB * d->PW, d->tpc, W); return VG_ERR_ARG; }
     return VG_OK;
 }
 
 extern "C" int64_t vg_conv_mm_stats_chunks(const vg_mm_desc* d, int32_t stats_per_group) {
-    if (!d || stats_per_group <= 0 || d->PD <= 0 || d->PDT <= 0) return -1;
-    return (int64_t)stats_per_group * vg_cdiv(d->PDT, d->PD) * MM_W;
+    if (!d || stats_per_group <= 0 || d->PD <= 0 || d->PDT <= 0 || d->PH <= 0 || (d->waves != 4 && d->waves != 8)) return -1;
+    const int PHB = (d->PHB > 0 && d->PHB < d->PH) ? d->PHB : d->PH;
+    return (int64_t)stats_per_group * vg_cdiv(d->PDT, d->PD) * vg_cdiv(d->PH, PHB) * d->waves;
 }
 
 extern "C" int vg_conv_mm(const vg_mm_desc* d, const float* x, const float* a_img, const int32_t* tau, const int32_t* dlt,
@@ -500,23 +532,24 @@ extern "C" int vg_conv_mm(const vg_mm_desc* d, const float* x, const float* a_im
     if ((in_scale == nullptr) != (in_shift == nullptr) || (in_scale && d->per_group <= 0)) { vg_set_error("vg_conv_mm: in_scale/in_shift/per_group inconsistent"); return VG_ERR_ARG; }
     if (stats_part && (stats_per_group <= 0 || d->N % stats_per_group)) { vg_set_error("vg_conv_mm: bad statistics arguments"); return VG_ERR_ARG; }
     p.has_pro = (d->relu_in || in_scale) ? 1 : 0;
-    p.x4 = ((d->IH * d->IW) % 4 == 0 && ((uintptr_t)x % 16) == 0) ? 1 : 0;   // every plane span then starts and ends on a 16-byte boundary
     hipStream_t s = (hipStream_t)stream;
     // persistent grid = the blocks that are resident at once (occupancy query of the chosen instance x 256 CUs), dealt over the
     // bps position slabs of a sample: every further block of a slab takes every nsplit-th sample
+    const int threads = d->waves * VG_WAVE;
     auto launch = [&](auto kernel) {
-        const int bpc = vg_blocks_per_cu((const void*)kernel, MM_T, shmem);
+        const int bpc = vg_blocks_per_cu((const void*)kernel, threads, shmem);
         int ns = (256 * bpc) / p.bps; if (ns < 1) ns = 1; if (ns > d->N) ns = d->N;
         p.nsplit = ns;
-        vg_launch(kernel, dim3(p.bps * p.nsplit), dim3(MM_T), shmem, s, x, a_img, (const int*)tau, (const int*)dlt, bias, in_scale, in_shift,
+        vg_launch(kernel, dim3(p.bps * p.nsplit), dim3(threads), shmem, s, x, a_img, (const int*)tau, (const int*)dlt, bias, in_scale, in_shift,
                   mask_src, y, stats_part, (int)(stats_part ? stats_per_group : 1), (int)stats_relu, p);
     };
-    const bool db = d->dbuf != 0, mk = mask_src != nullptr;
-    // OCC: 4 waves per SIMD (128 registers, two blocks per CU) where the per-(tile, step) operand offsets leave room for it
-#define MM_LAUNCH(NQ, TPC, K0, K1, K2, K3) { \
+    const bool db = d->dbuf != 0, mk = mask_src != nullptr, w4 = d->waves == 4;
+    // OCC: 4 waves per SIMD (128 registers: two 8-wave or four 4-wave blocks per CU) where the per-(tile, step) operand offsets leave room for it
+#define MM_LAUNCH_W(W, NQ, TPC, K0, K1, K2, K3) { \
         constexpr int OCC_ = (TPC * (K0 + K1 + K2 + K3) + 10 * TPC <= 96 && K0 > 0) ? 4 : 2; \
-        if (db) { if (mk) launch(conv_mm_k<NQ, TPC, K0, K1, K2, K3, true, OCC_, true>); else launch(conv_mm_k<NQ, TPC, K0, K1, K2, K3, true, OCC_, false>); } \
-        else    { if (mk) launch(conv_mm_k<NQ, TPC, K0, K1, K2, K3, false, OCC_, true>); else launch(conv_mm_k<NQ, TPC, K0, K1, K2, K3, false, OCC_, false>); } }
+        if (db) { if (mk) launch(conv_mm_k<W, NQ, TPC, K0, K1, K2, K3, true, OCC_, true>); else launch(conv_mm_k<W, NQ, TPC, K0, K1, K2, K3, true, OCC_, false>); } \
+        else    { if (mk) launch(conv_mm_k<W, NQ, TPC, K0, K1, K2, K3, false, OCC_, true>); else launch(conv_mm_k<W, NQ, TPC, K0, K1, K2, K3, false, OCC_, false>); } }
+#define MM_LAUNCH(NQ, TPC, K0, K1, K2, K3) { if (w4) MM_LAUNCH_W(4, NQ, TPC, K0, K1, K2, K3) else MM_LAUNCH_W(8, NQ, TPC, K0, K1, K2, K3) }
 #define MM_TPC(NQ, K0, K1, K2, K3) \
     { if (d->tpc <= 3) MM_LAUNCH(NQ, 3, K0, K1, K2, K3) else if (d->tpc <= 4) MM_LAUNCH(NQ, 4, K0, K1, K2, K3) else if (d->tpc <= 5) MM_LAUNCH(NQ, 5, K0, K1, K2, K3) \
       else if (d->tpc <= 6) MM_LAUNCH(NQ, 6, K0, K1, K2, K3) else MM_LAUNCH(NQ, 8, K0, K1, K2, K3) }
@@ -530,10 +563,12 @@ extern "C" int vg_conv_mm(const vg_mm_desc* d, const float* x, const float* a_im
     } else if (d->nq == 4 && d->tpc <= 4) {
         if (k[0] == 3 && k[1] == 2 && k[2] == 2 && k[3] == 1) MM_LAUNCH(4, 4, 3, 2, 2, 1)
         else if (k[0] == 2 && k[1] == 1 && k[2] == 1 && k[3] == 1) MM_LAUNCH(4, 4, 2, 1, 1, 1)
+        else if (k[0] == 2 && k[1] == 2 && k[2] == 2 && k[3] == 2) MM_LAUNCH(4, 4, 2, 2, 2, 2)          // 4x4x4 stride-2 transposed conv (82x98x70 geometry)
         else MM_LAUNCH(4, 4, 0, 0, 0, 0)
     } else { vg_set_error("vg_conv_mm: no kernel instance for %d classes x %d tiles per wave", d->nq, d->tpc); return VG_ERR_UNSUPPORTED; }
 #undef MM_TPC
 #undef MM_LAUNCH
+#undef MM_LAUNCH_W
     return vg_check_launch("conv_mm");
 }
 

@@ -867,9 +867,13 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
         // and 64-bit address arithmetic -- ~75 SALU instructions -- per DMA instruction)
         auto stage_a = [&](int c0, int nc, int slot0) {
             for (int c = 0; c < nc; ++c) {
-                const float* src = abase + ((size_t)(c0 + c) * d.AD + wave) * aplane + lane;
+                const float* src = abase + ((size_t)(c0 + c) * d.AD + wave) * aplane;
                 float* dst = lds + (slot0 + c) * p.a_slot + adst + wave * p.apl;
-                for (int pl = wave; pl < npl; pl += 4, src += 4 * (size_t)aplane, dst += 4 * p.apl) vg_dma_span(src, dst, cnt, lane);
+                for (int pl = wave; pl < npl; pl += 4, src += 4 * (size_t)aplane, dst += 4 * p.apl) {
+                    // (the 16-byte form, vg_dma_block, measured here: convt4 802 -> 793 us, convt5 508 -> 490, but convt2 224 -> 250-303 and the
+                    //  small layers 5-20 % slower -- spans of a few hundred floats: its head / tail pieces cost what the wide body saves)
+                    vg_dma_span(src + lane, dst, cnt, lane);
+                }
             }
         };
         if (RES) stage_a(0, CA, 0);
@@ -877,11 +881,13 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
         {
             const int nb = nrow * d.PW;
             const size_t bch_g = (size_t)d.PD * bplane;
-            const float* src_c = b + ((size_t)n * CB + wave) * bch_g + (size_t)pd0 * bplane + (size_t)ph0 * d.PW + lane;
+            const float* src_c = b + ((size_t)n * CB + wave) * bch_g + (size_t)pd0 * bplane + (size_t)ph0 * d.PW;
             float* dst_c = btile + wave * p.bch;
             for (int c = wave; c < CB; c += 4, src_c += 4 * bch_g, dst_c += 4 * p.bch) {
                 const float* src = src_c; float* dst = dst_c;
-                for (int dz = 0; dz < ndz; ++dz, src += bplane, dst += p.TPH * d.PW) vg_dma_span(src, dst, nb, lane);
+                for (int dz = 0; dz < ndz; ++dz, src += bplane, dst += p.TPH * d.PW) {
+                    vg_dma_span(src + lane, dst, nb, lane);
+                }
             }
         }
         VG_WS_ADD(2);                                                     // copy issue (a slot 0 + b tile)

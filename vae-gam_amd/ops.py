@@ -645,7 +645,7 @@ def mm_wins(plan):
     if USE_MM >= 2 or (plan.PDT + plan.PD - 1) // plan.PD == 1:
         return True
     if plan.mode == 'tconv':
-        return list(plan.ks) in ([3, 2, 2, 1], [2, 1, 1, 1])
+        return list(plan.ks) in ([3, 2, 2, 1], [2, 1, 1, 1], [2, 2, 2, 2])
     return plan.ks[0] in (7, 9)
 
 
@@ -1044,13 +1044,16 @@ def adam_step_(p, g, m, v, b1, b2, eps, step_scalars):
 # --------------------------------------------------------------------------- matrix-core convolution plans (vg_conv_mm)
 USE_MM = int(_os.environ.get('VG_CONV_MM', '1'))            # 0: off; 1: where it measured faster (mm_wins); 2: wherever a plan exists
 _MM_LDS_BUDGET = 150 * 1024
-_MM_LDS_HALF = 80 * 1024                                    # two blocks per CU
-# (mode, stride, CI, CO, kernel, read size, write size) -> (PD, cc, dbuf): tools/diag/mm_sweep.py at batch 64, 8 covariates
+_MM_LDS_CU = 160 * 1024                                     # LDS of a CU: what co-resident blocks share
+# (mode, stride, CI, CO, kernel, read size, write size) -> (waves, PD, PHB, cc, dbuf): tools/diag/mm_sweep.py at batch 64, 8 covariates
 _MM_TUNED = {
-    ('corr', 1, 16, 16, (3, 3, 3), (6, 8, 5), (8, 10, 7)): (4, 16, 0),          # convt1 forward 66.7 us (score's choice: 78)
-    ('corr', 1, 16, 16, (3, 3, 3), (8, 10, 7), (6, 8, 5)): (3, 16, 0),          # convt1 data gradient 37.8
-    ('corr', 2, 16, 16, (3, 3, 3), (16, 21, 14), (8, 10, 7)): (2, 8, 0),        # convt2 data gradient 83.2
-    ('corr', 1, 16, 8, (3, 3, 3), (17, 21, 14), (19, 23, 16)): (1, 8, 0),       # conv3 data gradient 61.6
+    ('corr', 1, 16, 16, (3, 3, 3), (6, 8, 5), (8, 10, 7)): (8, 4, 10, 16, 0),    # convt1 forward 66.7 us (score's choice: 78)
+    ('corr', 1, 16, 16, (3, 3, 3), (8, 10, 7), (6, 8, 5)): (8, 3, 8, 16, 0),     # convt1 data gradient 37.8
+    ('corr', 2, 16, 16, (3, 3, 3), (16, 21, 14), (8, 10, 7)): (8, 2, 10, 8, 0),   # convt2 data gradient 83.2
+    ('corr', 1, 16, 8, (3, 3, 3), (17, 21, 14), (19, 23, 16)): (8, 1, 23, 8, 0),  # conv3 data gradient 61.6
+    ('corr', 1, 8, 16, (3, 3, 3), (19, 23, 16), (17, 21, 14)): (8, 1, 21, 8, 0),  # conv3 forward 46 (score's choice, a 6-row slab: 51)
+    ('corr', 1, 8, 16, (3, 3, 3), (18, 23, 16), (16, 21, 14)): (8, 2, 11, 8, 1),  # convt3 data gradient 242 (whole planes: 254)
+    ('tconv', 2, 8, 8, (5, 3, 3), (18, 23, 16), (39, 47, 33)): (8, 2, 12, 8, 1),   # convt4 forward 610 (whole planes, single buffer: 656 in the same run)
 }
 _MM_WAVES = 8
 
@@ -1073,7 +1076,7 @@ class MmPlan:
     def desc(self, N, relu_in, per_group):
         d = _lib.MmDesc()
         for k in ('CI', 'CO', 'ID', 'IH', 'IW', 'OD', 'OH', 'OW', 'nq', 'PDT', 'PH', 'PW', 'PD', 'sdi', 'shi', 'swi', 'd0', 'LD', 'cc', 'sdo', 'sho',
-                  'swo', 'tpc', 'slack', 'dbuf'):
+                  'swo', 'tpc', 'slack', 'dbuf', 'PHB', 'hlo', 'hhi', 'waves'):
             setattr(d, k, int(getattr(self, k)))
         d.N, d.relu_in, d.per_group = int(N), int(bool(relu_in)), int(per_group)
         for q in range(4):
@@ -1225,39 +1228,58 @@ def _mm_build(mode, S, pad, CI, CO, K, isz, osz, widx, force=None):
         r0 += ks[q]
     aidx = np.concatenate(aidx)
     tpc_max = (8 if max(ks) <= 12 else 3) if nq == 1 else 4        # registers: one operand offset per (tile, k-step)
-    # Tile choice.  Measured (tools/diag/mm_sweep.py, MI355X): what pays is TWO co-resident blocks per CU -- their input waits,
-    # prologues, barriers and epilogues interleave with each other's matrix phases -- i.e. at most half the LDS (single-buffered input
-    # where double does not fit) and at most 3 tiles per wave (the 128-register instances); then full accumulator columns, a small halo
-    # and large channel chunks.  _MM_TUNED pins the bench geometries where the sweep found a better tile than this score.
+    hlo, hhi = int(dlt[:, :, 1].min()), int(dlt[:, :, 1].max())
+    # Tile choice: a block = W waves on PD position planes x PHB position rows (x all PW columns).  Measured (tools/diag/mm_sweep.py,
+    # MI355X): what pays is SEVERAL co-resident blocks per CU -- their input waits, prologues, barriers and epilogues interleave with
+    # each other's matrix phases -- i.e. a small LDS footprint (single-buffered input, row slabs instead of whole planes) and at most
+    # 3 tiles per wave (the 128-register instances: 4 waves per SIMD); then full accumulator columns, a small halo and large channel
+    # chunks.  _MM_TUNED pins the bench geometries where the sweep found a better tile than this score.
     tuned = _MM_TUNED.get((mode, S, CI, CO, tuple(K), tuple(isz), tuple(osz))) if force is None else None
+    pin = force or tuned
     cands = []
-    for PD in range(min(PDT, 16), 0, -1):
-        npos = PD * PH * PW
-        tpc = (npos + _MM_WAVES * 16 - 1) // (_MM_WAVES * 16)
-        if tpc > tpc_max:
-            continue
-        LD = ld_of(PD)
-        CHP = 64 + ((LD * IHW + 63) // 64) * 64
-        bps = (PDT + PD - 1) // PD
-        for cc in ([CI] if nq > 1 else [c for c in range(CI, 0, -1) if CI % c == 0]):
-            for dbuf in (1, 0):
-                if (force or tuned) and (PD, cc, dbuf) != tuple(force or tuned):
+    for W in (8, 4):
+        for PD in range(min(PDT, 16), 0, -1):
+            LD = ld_of(PD)
+            for nslab in (1, 2, 3, 4, 6, 8, 12):
+                PHB = (PH + nslab - 1) // nslab
+                if nslab > 1 and ((PH + PHB - 1) // PHB != nslab or PHB < 2):
                     continue
-                lds = (((aidx.size + 63) // 64) * 64 + rows * 64 + (1 + dbuf) * cc * CHP + 64) * 4
-                if lds > _MM_LDS_BUDGET:
+                npos = PD * PHB * PW
+                tpc = (npos + W * 16 - 1) // (W * 16)
+                if tpc > tpc_max:
                     continue
-                two = lds <= _MM_LDS_HALF and (tpc <= 3 or nq > 1)
-                util = npos / float(tpc * _MM_WAVES * 16) * (PDT / float(bps * PD))          # filled accumulator columns
-                halo = (PD * sdi) / float(LD)                                                  # useful share of the staged planes
-                fill = min(1.0, (bps * max(1, 256 // bps)) / 256.0)
-                score = util * (0.5 + 0.5 * halo) * fill * (0.9 + 0.1 * cc / float(CI)) * (1.0 if two else 0.6) * (1.0 if (dbuf or two) else 0.9)
-                cands.append((score, PD, LD, cc, tpc, dbuf))
+                rows_max = min((PHB - 1) * shi + (hhi - hlo) + 1, IH)
+                whole = (nslab == 1 and hlo <= 0 and (PH - 1) * shi + hhi + 1 >= IH)
+                LPH = IHW if whole else ((rows_max * IW + 3) // 4) * 4 + 4
+                CHP = 64 + ((LD * LPH + 63) // 64) * 64
+                bps = ((PDT + PD - 1) // PD) * nslab
+                for cc in ([CI] if nq > 1 else [c for c in range(CI, 0, -1) if CI % c == 0]):
+                    for dbuf in (1, 0):
+                        if pin and (W, PD, PHB, cc, dbuf) != tuple(pin):
+                            continue
+                        lds = (((aidx.size + 63) // 64) * 64 + rows * 64 + (1 + dbuf) * cc * CHP + 64) * 4
+                        if lds > _MM_LDS_BUDGET:
+                            continue
+                        per_simd = 4 if (tpc <= 3 or nq > 1) else 2                               # waves per SIMD the instance's registers allow
+                        nblk = min(_MM_LDS_CU // lds, per_simd * 4 // W)
+                        if nblk < 1:
+                            continue
+                        util = npos / float(tpc * W * 16) * (PDT / float(((PDT + PD - 1) // PD) * PD)) * (PH / float(nslab * PHB))   # filled accumulator columns
+                        halo = ((PD * sdi) / float(LD)) * min(1.0, (PHB * shi) / float(rows_max))        # useful share of the staged elements
+                        wps = nblk * W // 4                                                        # co-resident waves per SIMD
+                        occ = {1: 0.45, 2: 0.6, 3: 0.8}.get(wps, 1.0)
+                        # whole planes in 8-wave blocks measured best wherever they fit (41x49x35: row slabs / 4-wave blocks 3-20 % slower:
+                        # more halo rows, fewer waves to balance a block's tiles over); slabs are what lets the 82x98x70 planes in at all
+                        shape = (1.0 if nslab == 1 else 0.85) * (1.0 if W == 8 else 0.9)
+                        score = util * (0.5 + 0.5 * halo) * (0.9 + 0.1 * cc / float(CI)) * occ * shape * (1.0 if (dbuf or nblk >= 2) else 0.9)
+                        cands.append((score, PD, LD, cc, tpc, dbuf, PHB, W))
     if not cands:
         return None
-    _, PD, LD, cc, tpc, dbuf = max(cands, key=lambda c: (round(c[0], 9), c[3], -c[5]))
+    _, PD, LD, cc, tpc, dbuf, PHB, W = max(cands, key=lambda c: (round(c[0], 9), c[3], -c[5]))
     tpc = {1: (3 if tpc <= 3 else tpc if tpc <= 6 else 8), 4: 4}[nq]
     return MmPlan(CI=CI, CO=CO, ID=ID, IH=IH, IW=IW, OD=OD, OH=OH, OW=OW, nq=nq, ks=ks, PDT=PDT, PH=PH, PW=PW, PD=PD, sdi=sdi, shi=shi,
                   swi=swi, d0=d0, LD=LD, cc=cc, sdo=sdo, sho=sho, swo=swo, od0=od0, oh0=oh0, ow0=ow0, tpc=tpc, slack=slack, dbuf=dbuf,
+                  PHB=PHB, hlo=hlo, hhi=hhi, waves=W,
                   tau=tau.reshape(-1), dlt=dlt.reshape(-1), aidx=aidx, mode=mode)
 
 
