@@ -36,6 +36,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 FP32_PEAK_TF = 157.3
 ALG_BYTES_PER_VOL = {3: 69.6e6, 8: 139.2e6, 12: 194.8e6}
 ALG_GFLOP_PER_VOL = {3: 1.600, 8: 3.241, 12: 4.555}
+HIRES_ALG_BYTES_PER_VOL, HIRES_ALG_GFLOP_PER_VOL = 1739e6, 51.40   # 82x98x70, 12 covariates
 
 
 def host_threads():
@@ -120,6 +121,8 @@ def main():
     ap.add_argument('--cpu-steps', type=int, default=5, help='timed CPU-oracle steps (median; after 2 warm-ups, SURVEY 8d); ~5 s each at batch 64 / 8 covariates on 16 threads')
     ap.add_argument('--eager', action='store_true', help='launch kernels eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--kernel-table', action='store_true', help='print the per-kernel HIP-event table to stderr')
+    ap.add_argument('--hires', action='store_true', help="BASELINE configs[4]'s per-GPU slice: 82x98x70 volumes, 12 covariates, 64 GP inducing points "
+                    '(gp_jitter 1e-4, SURVEY H2), batch 64 per GPU; --batch / --steps as given (defaults here: 64, 10 steps after 3 warm-ups)')
     a = ap.parse_args()
 
     import numpy as np
@@ -145,14 +148,21 @@ def main():
         from vae_gam_amd import dp as dpmod
         dp = dpmod.DataParallelContext.from_env()
 
+    if a.hires:
+        a.covariates = 12
+        if a.steps == 30 and a.warmup == 5:
+            a.steps, a.warmup = 10, 3                                    # 64 volumes of 82x98x70 x 13 decoder passes: ~0.14 s per step
     B, C = a.batch, a.covariates
     # weak scaling: 2 synthetic subjects per GPU (configs[3]: 16 subjects on 8 GPUs), and always at least two global minibatches
     a.subjects = max(a.subjects, 2 * world)
-    while a.subjects * 98 < 2 * B * world:
+    while not a.hires and a.subjects * 98 < 2 * B * world:
         a.subjects += 1
-    ds = synthetic.make_dataset(num_subjects=a.subjects, vols_per_subject=98, num_covariates=C, seed=0)
+    img = (82, 98, 70) if a.hires else (41, 49, 35)
+    vps = 98 if not a.hires else max(2 * B * world // a.subjects + 1, 16)       # hi-res: just enough volumes for two global minibatches (0.56 M floats each)
+    ds = synthetic.make_dataset(num_subjects=a.subjects, vols_per_subject=vps, num_covariates=C, seed=0, img_shape=img)
     torch.manual_seed(1)                                             # CLI default seed (multsubj_reg_run_GP.py:31)
-    model = VAE(num_covariates=C, glm_maps=ds['glm'], xu_ranges=ds['xu_ranges'], device_name='cuda', data_parallel=dp)
+    model = VAE(num_covariates=C, glm_maps=ds['glm'], xu_ranges=ds['xu_ranges'], device_name='cuda', data_parallel=dp,
+                **(dict(img_shape=img, num_inducing_pts=64, gp_jitter=1e-4) if a.hires else {}))
     data = DeviceResidentData(torch.from_numpy(ds['volumes']), torch.from_numpy(ds['covariates']),
                               torch.from_numpy(ds['subjid']), batch_size=B * world, shuffle=True, seed=0, device=dev,
                               rank=rank, world=world)
@@ -216,7 +226,7 @@ def main():
         cands = sorted(f for f in os.listdir(os.path.join(ROOT, 'profiles')) if f.endswith('_traffic_by_layer.json'))
         traffic_tab = json.load(open(os.path.join(ROOT, 'profiles', cands[-1])))
         meta = traffic_tab.get('_meta', {})
-        traffic_ok = (meta.get('kernel_source_sha') == kernel_source_sha() and meta.get('batch') == B and meta.get('covariates') == C)
+        traffic_ok = (meta.get('kernel_source_sha') == kernel_source_sha() and meta.get('batch') == B and meta.get('covariates') == C and not a.hires)
     except Exception:
         pass
     for tot, key, n in rows:
@@ -241,7 +251,7 @@ def main():
         print('sum of HIP kernel time %.3f ms/step (events), wall %.3f ms/step (%s)' % (tsum / prof_steps, ms_per_step, 'hipGraph replay' if graphed else 'eager'), file=sys.stderr)
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.hires:     # (hi-res: one CPU step is minutes; the 41x49x35 line carries the CPU baseline)
         sys.path.insert(0, os.path.join(ROOT, 'oracle'))
         import bridge
         import vaegam_oracle as O
@@ -275,24 +285,26 @@ def main():
 
     if rank == 0:
         out = {
-            'metric': 'fMRI volumes/sec/train-step (41x49x35)', 'value': round(value, 1), 'unit': 'volumes/s',
+            'metric': 'fMRI volumes/sec/train-step (%s)' % ('82x98x70' if a.hires else '41x49x35'), 'value': round(value, 1), 'unit': 'volumes/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': ('configs[1]' if (B, C) == (32, 3) else 'configs[2] full VAE-GAM' if (B, C) == (64, 8) else 'custom') +
-                                   ': B=%d/GPU C=%d, 41x49x35, %d subj x 98 vol synthetic checker, fwd+bwd+Adam, %s'
-                                   % (B, C, a.subjects, 'hipGraph replay' if graphed else 'eager launches'),
+            'config': {'workload': (("configs[4] per-GPU slice (high-res stress: 64 GP inducing points, gp_jitter 1e-4)" if a.hires else 'configs[1]' if (B, C) == (32, 3)
+                                     else 'configs[2] full VAE-GAM' if (B, C) == (64, 8) else 'custom') +
+                                    ': B=%d/GPU C=%d, %s, %d subj x %d vol synthetic checker, fwd+bwd+Adam, %s'
+                                    % (B, C, 'x'.join(str(v) for v in img), a.subjects, vps, 'hipGraph replay' if graphed else 'eager launches')),
                        'detail': 'BASELINE.json configs[%s]: synthetic checker control (Large3 glyph, block design), GP regressors on the '
                                  'continuous covariates, HRF on task, GLM regulariser on; gain / GP algebra on device in fp64'
-                                 % ('2' if (B, C) == (64, 8) else '1' if (B, C) == (32, 3) else '-'),
+                                 % ('4 (its 1/8 share)' if a.hires else '2' if (B, C) == (64, 8) else '1' if (B, C) == (32, 3) else '-'),
                        'global_batch': B * world, 'covariates': C, 'parallelism': 'dp%d' % world,
                        **({'dp': ('batch-norm statistics and loss normalisation over the global minibatch (all-reduced), one gradient all-reduce; dp_gain=%s: ' % model.dp_gain) +
                                 ('gains drawn per rank from its own slice (block-diagonal approximation of the joint B x B gain draw; the HRF runs along the global batch '
                                  'across ranks) -- NOT the 1-rank global-batch computation, which dp_gain=global reproduces at O(B_global^2..3) serial cost per rank'
                                  if model.dp_gain == 'local' else 'joint gain draw of the global minibatch on every rank = the 1-rank global-batch step')} if world > 1 else {})},
             'roofline': roofline,
-            'step_roofline': {'hbm_frac': round(value / world * ALG_BYTES_PER_VOL.get(C, 0) / (HBM_PEAK_GBS * 1e9), 4),
-                              'fp32_frac': round(value / world * ALG_GFLOP_PER_VOL.get(C, 0) / (FP32_PEAK_TF * 1e3), 4),
-                              'alg_bytes_per_volume': ALG_BYTES_PER_VOL.get(C), 'gflop_per_volume': ALG_GFLOP_PER_VOL.get(C)},
+            'step_roofline': {'hbm_frac': round(value / world * (HIRES_ALG_BYTES_PER_VOL if a.hires else ALG_BYTES_PER_VOL.get(C, 0)) / (HBM_PEAK_GBS * 1e9), 4),
+                              'fp32_frac': round(value / world * (HIRES_ALG_GFLOP_PER_VOL if a.hires else ALG_GFLOP_PER_VOL.get(C, 0)) / (FP32_PEAK_TF * 1e3), 4),
+                              'alg_bytes_per_volume': HIRES_ALG_BYTES_PER_VOL if a.hires else ALG_BYTES_PER_VOL.get(C),
+                              'gflop_per_volume': HIRES_ALG_GFLOP_PER_VOL if a.hires else ALG_GFLOP_PER_VOL.get(C)},
             'cpu_baseline': cpu,
         }
         print(json.dumps(out), flush=True)

@@ -244,6 +244,9 @@ struct CorrPlaneParams {
     int CCH;                    // channels per chunk
     int ch_floats;              // LDS floats per channel (LD*IH*IW rounded up)
     int nbuf;                   // 2: the next chunk's planes are DMA'd behind this chunk's FMAs (one barrier per chunk)
+    // row slabs (planes too large for one block -- the 82x98x70 geometry): a block covers OHB output rows of its planes and stages
+    // the LH input rows they touch, one contiguous span per plane at the LDS plane pitch lplane
+    int OHB, nhb, LH, lplane;
 };
 constexpr int PLANE_SLACK = 8;  // floats in front of the LDS buffer: a window may start at iw = -pad
 
@@ -264,17 +267,24 @@ corr3d_plane_k(const float* __restrict__ x, const float* __restrict__ wpk, const
     const int n = blockIdx.y;
     const int CO = COC ? COC : d.CO;                 // compile-time channel count: per-tap weight offsets become load immediates
     const int co0 = blockIdx.z * COT;
-    const int tdi = blockIdx.x;
+    const int tdi = blockIdx.x / p.nhb, hb = blockIdx.x % p.nhb;
     const int wg = tid % p.TWG; const int thl = (tid / p.TWG) % p.TH; const int tdl = tid / (p.TWG * p.TH);
-    const int od0 = tdi * p.TD * TDt;
-    const int od_t = od0 + tdl * TDt, oh_t = thl * THt, ow_t = wg * TW;
-    const bool active = tdl < p.TD && od_t < d.OD && oh_t < d.OH && ow_t < d.OW;
+    const int od0 = tdi * p.TD * TDt, oh0 = hb * p.OHB;
+    const int od_t = od0 + tdl * TDt, oh_t = oh0 + thl * THt, ow_t = wg * TW;
+    const bool active = tdl < p.TD && od_t < d.OD && thl * THt < p.OHB && oh_t < d.OH && ow_t < d.OW;
     const int plane = d.IH * d.IW;
+    // staged input rows of every plane: [r_lo, r_hi) = the rows the slab's windows touch, clipped to the tensor; a plane's LDS slot
+    // starts with row r_lo.  Whole planes (one slab, tensor pitch): r_lo = 0, r_hi = IH, one span per channel.
+    const int ih0 = oh0 * S - d.pad_h;
+    const int r_lo = max(ih0, 0), r_hi = min(ih0 + p.LH, d.IH);
+    const int lplane = p.lplane;
+    const bool flat = (r_lo == 0 && r_hi == d.IH && lplane == plane);
     // input planes [ip0, ip0 + LD) clipped to the tensor; local plane l <-> input plane ip0 + l
     const int ip0 = od0 * S - d.pad_d;
     const int pl_lo = max(ip0, 0), pl_hi = min(ip0 + p.LD, d.ID);          // valid planes [pl_lo, pl_hi)
-    const int nfl = max(pl_hi - pl_lo, 0) * plane;                          // floats to copy per channel
-    const int dst0 = (pl_lo - ip0) * plane;                                 // where they land inside the channel slot
+    const int npl = max(pl_hi - pl_lo, 0);
+    const int nfl = flat ? npl * plane : max(r_hi - r_lo, 0) * d.IW;        // floats per span (flat: one span per channel, else one per plane)
+    const int dst0 = (pl_lo - ip0) * lplane;                                // where the first staged plane lands inside the channel slot
 
     // this thread's window: LDS offsets of its rows (row index clamped, masked below) and validity
     // Validity of the window's rows / columns.  VEC_MASK: as VECTOR values -- a row factor (1 or 0) folded into the prologue's scale
@@ -295,7 +305,7 @@ corr3d_plane_k(const float* __restrict__ x, const float* __restrict__ wpk, const
             rokf[dz][hy] = VEC_MASK ? vg_opaque(rok[dz][hy] ? 1.f : 0.f) : 0.f;
             // VEC_MASK multiplies instead of selecting: clamp to a plane that WAS staged (0 * real data is 0, 0 * LDS garbage may be NaN)
             const int lp = VEC_MASK ? clampi(id, pl_lo, max(pl_hi - 1, pl_lo)) - ip0 : clampi(id - ip0, 0, p.LD - 1);
-            roff[dz][hy] = lp * plane + clampi(ih, 0, d.IH - 1) * d.IW + iw_t;
+            roff[dz][hy] = lp * lplane + (clampi(ih, r_lo, max(r_hi - 1, r_lo)) - r_lo) * d.IW + iw_t;
             // NOPRO (no ReLU / affine on the input: the data-gradient launches): a row outside the tensor reads the zeroed tail of the
             // channel slot instead, so an element costs ONE v_and (column mask) instead of max + fma + and
             if (NOPRO && !rok[dz][hy]) roff[dz][hy] = p.ch_floats - 32;
@@ -324,13 +334,15 @@ corr3d_plane_k(const float* __restrict__ x, const float* __restrict__ wpk, const
     const int g = (in_scale != nullptr) ? n / d.per_group : 0;
     const float lo = d.relu_in ? 0.f : -__builtin_inff();
     const size_t vol = (size_t)plane * d.ID;
-    const float* __restrict__ xsrc = x + (size_t)n * d.CI * vol + (size_t)pl_lo * plane;
+    const float* __restrict__ xsrc = x + (size_t)n * d.CI * vol + (size_t)pl_lo * plane + (size_t)r_lo * d.IW;
     auto stage = [&](int c0, float* buf) {
         const int cc = min(p.CCH, d.CI - c0);
+        const int nw = (int)(blockDim.x / VG_WAVE);
         for (int c = 0; c < cc; ++c) {
             const float* src = xsrc + (size_t)(c0 + c) * vol;
             float* dst = buf + c * p.ch_floats + dst0;
-            vg_dma_block(src, dst, nfl, wave, (int)(blockDim.x / VG_WAVE), lane);
+            if (flat) vg_dma_block(src, dst, nfl, wave, nw, lane);
+            else for (int pl = 0; pl < npl; ++pl) vg_dma_block(src + (size_t)pl * plane, dst + pl * lplane, nfl, wave, nw, lane);
         }
     };
     const int buf_floats = p.CCH * p.ch_floats;
@@ -459,21 +471,33 @@ template <int COT, int KD, int KH, int KW, int S, int TDt, int THt, int TW, int 
 int launch_corr_plane(const vg_conv_desc* d, const float* x, const float* wpk, const float* bias, const float* in_scale,
                       const float* in_shift, const float* mask_src, float* y, hipStream_t s) {
     CorrPlaneParams p; p.d = *d;
-    const int gw = vg_cdiv(d->OW, TW), gh = vg_cdiv(d->OH, THt), gd = vg_cdiv(d->OD, TDt);
-    if (gw * gh > 256) return -1;                        // one block must span all of H and W
-    p.TWG = gw; p.TH = gh;
+    const int gw = vg_cdiv(d->OW, TW), gd = vg_cdiv(d->OD, TDt);
+    if (gw > 256) return -1;
     const int plane = d->IH * d->IW;
     const size_t budget = 48 * 1024;
+    // rows: one block spans all of H where the threads and ONE channel's planes allow it (every layer of the 41x49x35 network);
+    // otherwise the fewest row slabs that do (82x98x70)
+    int nhb = 1, ohb = d->OH, gh = vg_cdiv(d->OH, THt), lh = d->IH, lplane = plane;
+    for (;; ++nhb) {
+        ohb = vg_cdiv(vg_cdiv(d->OH, nhb), THt) * THt;
+        gh = ohb / THt;
+        if (nhb > 1) { lh = (ohb - 1) * S + KH; if (lh > d->IH) lh = d->IH; lplane = ((lh * d->IW + 3) / 4) * 4; }
+        const size_t need = ((size_t)((TDt - 1) * S + KD) * lplane + 64 + 64) * sizeof(float);     // one tile of output planes deep, one channel
+        if (gw * gh <= 256 && need + (PLANE_SLACK + 64) * sizeof(float) <= budget) break;
+        if (ohb <= THt) return -1;
+    }
+    nhb = vg_cdiv(d->OH, ohb);
+    p.TWG = gw; p.TH = gh; p.OHB = ohb; p.nhb = nhb; p.LH = (nhb == 1) ? d->IH + d->pad_h : lh; p.lplane = lplane;
     int td = 256 / (gw * gh);
     if (td > gd) td = gd;
     for (; td >= 1; --td) {
         const int LD = (td * TDt - 1) * S + KD;
-        if (((size_t)LD * plane + 64) * sizeof(float) + 64 <= budget) break;
+        if (((size_t)LD * lplane + 64) * sizeof(float) + 64 <= budget) break;
     }
     if (td < 1) return -1;
     p.TD = td; p.LD = (td * TDt - 1) * S + KD;
     p.tilesD = vg_cdiv(gd, p.TD);
-    p.ch_floats = ((p.LD * plane + 63) / 64) * 64 + 64;  // slot per channel: whole 256-byte DMA groups + slack for window over-reads
+    p.ch_floats = ((p.LD * lplane + 63) / 64) * 64 + 64;  // slot per channel: whole 256-byte DMA groups + slack for window over-reads
     // Two buffers (the next chunk in flight behind this chunk's FMAs, one barrier per chunk) only for the large-tile instances.
     // Measured on MI355X: no gain where the chunk is small (convt3/convt4: 3 blocks per CU already hide the fill) and a
     // loss where it doubles a 25 KB slot (convt5 forward 244 -> 341 us: only two 52 KB blocks fit a CU).
@@ -488,7 +512,7 @@ int launch_corr_plane(const vg_conv_desc* d, const float* x, const float* wpk, c
     const size_t shmem = (size_t)p.ch_floats * cch * p.nbuf * sizeof(float) + (PLANE_SLACK + 64) * sizeof(float);
     if (d->CO % COT) { vg_set_error("corr3d: CO=%d not a multiple of %d", d->CO, COT); return VG_ERR_UNSUPPORTED; }
     const int threads = vg_cdiv(p.TWG * p.TH * p.TD, VG_WAVE) * VG_WAVE;
-    dim3 grid(p.tilesD, d->N, d->CO / COT);
+    dim3 grid(p.tilesD * p.nhb, d->N, d->CO / COT);
     if constexpr (KD == 5) {                                     // (the instances built with vector masks; the one-channel one always has a prologue)
         if (in_scale == nullptr && !d->relu_in) {
             vg_launch(corr3d_plane_k<COT, KD, KH, KW, S, TDt, THt, TW, COC, true>, grid, dim3(threads), shmem, s,

@@ -1228,7 +1228,7 @@ int dispatch(const vg_wgrad_desc* d, const float* a, const float* b, const float
 #define PLANE(CA, TC, KD, KH, KW, S) \
     { { int r_ = launch_rows<CA, TC, KD, KH, KW, S, false>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; } \
       int r_ = launch_plane<CA, TC, KD, KH, KW, S, false>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; }
-    if (d->CB <= 16 && d->PW <= 64) {
+    if (d->CB <= 16 && d->PW <= 128) {
         if (k333 && d->CA == 1 && d->stride == 1) PLANE(1, 2, 3, 3, 3, 1);
         if (k333 && d->CA == 16 && d->stride == 2 && (d->pad_d || d->pad_h || d->pad_w))
             { { int r_ = launch_rows<16, 2, 3, 3, 3, 2, true>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; }
@@ -1269,7 +1269,7 @@ static int grouped_dispatch(const vg_wgrad_desc* d, const float* a, const float*
         vg_set_error("vg_wgrad3d_grouped: bad shape"); return VG_ERR_ARG;
     }
     const bool k333 = d->KD == 3 && d->KH == 3 && d->KW == 3;
-    if (k333 && d->CA == 1 && d->stride == 1 && !d->pad_d && !d->pad_h && !d->pad_w && d->PW <= 64) {
+    if (k333 && d->CA == 1 && d->stride == 1 && !d->pad_d && !d->pad_h && !d->pad_w && d->PW <= 128) {
         int r_ = launch_rows<1, 2, 3, 3, 3, 1, false>(d, a, b, in_scale, in_shift, ws, out, s, ws_only, 0, 1);
         if (r_ >= 0) return r_;
     }

@@ -829,7 +829,19 @@ class LinearAct(torch.autograd.Function):
         bias = ctx.bias_ref
         if ctx.relu:
             gy = torch.ops.aten.threshold_backward(gy, y, 0.0)
-        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            if gy.is_cuda and gy.shape[1] >= 16384:
+                # a reduction over tens of thousands of columns into a (rows x 200) result (fc8 at 82x98x70: 208 x 66,560 x 200): rocBLAS
+                # picks a kernel without split-K there -- 3.6 ms against hipBLASLt's 0.25 ms (tools/diag/gemm_probe.py), 10 % of that step
+                prev = torch.backends.cuda.preferred_blas_library()
+                torch.backends.cuda.preferred_blas_library('cublaslt')
+                try:
+                    gx = gy @ weight
+                finally:
+                    torch.backends.cuda.preferred_blas_library(prev)
+            else:
+                gx = gy @ weight
         wg, bg = _grad_buf(weight), _grad_buf(bias)
         gw = gb = None
         if wg is not None and bg is not None:
