@@ -298,7 +298,7 @@ def main():
                        'global_batch': B * world, 'covariates': C, 'parallelism': 'dp%d' % world,
                        **({'dp': ('batch-norm statistics and loss normalisation over the global minibatch (all-reduced), one gradient all-reduce; dp_gain=%s: ' % model.dp_gain) +
                                 ('gains drawn per rank from its own slice (block-diagonal approximation of the joint B x B gain draw; the HRF runs along the global batch '
-                                 'across ranks) -- NOT the 1-rank global-batch computation, which dp_gain=global reproduces at O(B_global^2..3) serial cost per rank'
+                                 'across ranks) -- NOT the 1-rank global-batch computation, which the default dp_gain=global reproduces'
                                  if model.dp_gain == 'local' else 'joint gain draw of the global minibatch on every rank = the 1-rank global-batch step')} if world > 1 else {})},
             'roofline': roofline,
             'step_roofline': {'hbm_frac': round(value / world * (HIRES_ALG_BYTES_PER_VOL if a.hires else ALG_BYTES_PER_VOL.get(C, 0)) / (HBM_PEAK_GBS * 1e9), 4),

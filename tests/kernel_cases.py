@@ -232,6 +232,52 @@ def run_fused_stats_case(dev, spec, isz, groups=2, per_group=3, seed=0):
     np.testing.assert_allclose(pbg.cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(want.abs().max()))
 
 
+def run_conv_mm_plan_case(dev, kind, force, seed=0):
+    """vg_conv_mm with a PINNED tile -- waves per workgroup, PD planes x PHB rows per block, channels per chunk, single / double
+    buffered input -- against torch's own convolution: the row-slab staging (one span per plane, padded LDS pitch), the 4-wave
+    workgroups, the counted-vmcnt single-buffer order, the ReLU mask fetched ahead of the last matrix phase and the per-group-run
+    statistics flush must all give what the whole-plane 8-wave plan gives.
+    kind: 'convt3_fwd' (16->8, 3x3x3 stride-1 transposed conv as a padded correlation, prologue = ReLU + batch-norm affine),
+          'convt3_bwd' (its data gradient: 8->16 correlation, ReLU mask of the producer fused into the epilogue),
+          'convt4_fwd' (8->8, 5x3x3 stride-2 transposed conv: 4 output-parity classes, statistics of the next batch norm)."""
+    g = torch.Generator().manual_seed(seed)
+    per_group, groups = 3, 2
+    N = per_group * groups
+    if kind == 'convt4_fwd':
+        spec = ops.ConvSpec('convt', 8, 8, (5, 3, 3), 2); isz = (5, 9, 6)
+    else:
+        spec = ops.ConvSpec('convt', 16, 8, (3, 3, 3), 1); isz = (5, 9, 6)
+    osz = spec.out_size(isz)
+    x = torch.randn((N, spec.ci) + isz, generator=g)
+    w = 0.2 * torch.randn((spec.ci, spec.co) + tuple(spec.k), generator=g)
+    b = 0.1 * torch.randn(spec.co, generator=g)
+    sc = 1 + 0.3 * torch.randn(groups * spec.ci, generator=g); sh = 0.2 * torch.randn(groups * spec.ci, generator=g)
+    if kind.endswith('_fwd'):
+        h = torch.relu(x) * sc.view(groups, 1, spec.ci, 1, 1, 1).expand(groups, per_group, spec.ci, 1, 1, 1).reshape(N, spec.ci, 1, 1, 1) \
+            + sh.view(groups, 1, spec.ci, 1, 1, 1).expand(groups, per_group, spec.ci, 1, 1, 1).reshape(N, spec.ci, 1, 1, 1)
+        want = F.conv_transpose3d(h, w, b, spec.stride)
+        plan = ops.mm_plan(spec, 'fwd', isz, None, force=force)
+        assert plan is not None, force
+        nb = per_group if kind == 'convt4_fwd' else None
+        got = ops.conv_mm(x.to(dev), plan, plan.gather(w.to(dev)), b.to(dev), True, sc.to(dev), sh.to(dev), per_group, None, nb)
+        if nb:
+            got, part = got
+            gamma = torch.ones(spec.co, device=dev); beta = torch.zeros(spec.co, device=dev)
+            fused = ops.bn_stats(got, gamma, beta, True, per_group, pre=part)
+            plain = ops.bn_stats(got, gamma, beta, True, per_group)
+            for a_, b_, nm in zip(fused, plain, ('scale', 'shift', 'mean', 'rstd')):
+                np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg='%s %r' % (nm, force))
+    else:
+        dy = torch.randn((N, spec.co) + osz, generator=g)
+        xm = torch.randn((N, spec.ci) + isz, generator=g)              # the producer's pre-activation: ReLU mask of the data gradient
+        want = F.conv3d(dy, w) * (xm > 0)                              # d/dx of conv_transpose3d(x, w) = correlation of dy with w
+        plan = ops.mm_plan(spec, 'bwd', osz, isz, force=force)
+        assert plan is not None, force
+        got = ops.conv_mm(dy.to(dev), plan, plan.gather(w.to(dev)), None, False, None, None, 1, xm.to(dev))
+    assert (plan.waves, plan.PD, plan.PHB, plan.cc, plan.dbuf) == tuple(force)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-4, err_msg='%s %r' % (kind, force))
+
+
 def run_adam_case(dev, dtype, n=5000, steps=3, seed=0):
     g = torch.Generator().manual_seed(seed)
     p0 = torch.randn(n, generator=g, dtype=dtype)

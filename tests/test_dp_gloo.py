@@ -82,7 +82,7 @@ def test_two_ranks_equal_one_rank_global_batch(tmp_path):
 
 
 def test_local_gain_mode_draws_each_ranks_slice_from_its_own_covariance(tmp_path):
-    """dp_gain='local' (the default under data parallelism): a rank draws the gains of ITS slice from that slice's own B x B gain
+    """dp_gain='local' (an option; the default is the exact joint draw, 'global'): a rank draws the gains of ITS slice from that slice's own B x B gain
     covariance (its columns of the noise tape; the block-diagonal approximation of the joint draw, cost independent of the number of
     ranks), and the HRF of the neural covariates then runs along the GLOBAL batch index across the slices (ops.HrfAcrossRanks) -- it
     does not restart at a rank boundary.  Batch-norm statistics, the loss normalisation and the gradient sum stay global: replicas

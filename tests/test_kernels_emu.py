@@ -80,6 +80,20 @@ def test_cholesky(n):
     K.run_cholesky_case('cpu', batch=3, n=n)
 
 
-@pytest.mark.parametrize('B,n,jitter', [(12, 6, 0.0), (17, 6, 0.0), (7, 12, 1e-5)])
+@pytest.mark.parametrize('B,n,jitter', [(12, 6, 0.0), (17, 6, 0.0), (7, 12, 1e-5), (130, 6, 0.0)])    # 130: the large-batch path (blocked Cholesky, slab solves)
 def test_gain_block_matches_float64_oracle(B, n, jitter):
     K.run_gain_case('cpu', B=B, n=n, jitter=jitter, seed=B)
+
+
+@pytest.mark.parametrize('kind,force', [
+    ('convt3_fwd', (8, 2, 11, 8, 0)),      # whole planes (PHB = PH = 11), 8 waves, two channel chunks, single-buffered
+    ('convt3_fwd', (8, 2, 4, 16, 1)),      # row slabs of 4 rows (3 slabs), double-buffered
+    ('convt3_fwd', (4, 1, 6, 4, 0)),       # 4-wave workgroups, 2 slabs, 4 chunks
+    ('convt3_bwd', (8, 1, 9, 8, 0)),       # data gradient, whole planes
+    ('convt3_bwd', (4, 2, 3, 4, 1)),       # data gradient, 4 waves, slabs of 3 rows, mask + double buffer
+    ('convt4_fwd', (8, 1, 10, 8, 0)),      # 4 parity classes, whole planes, statistics
+    ('convt4_fwd', (8, 2, 5, 8, 1)),       # ... row slabs
+    ('convt4_fwd', (4, 1, 4, 8, 0)),       # ... 4-wave workgroups
+])
+def test_conv_mm_pinned_tiles(kind, force):
+    K.run_conv_mm_plan_case('cpu', kind, force)

@@ -19,16 +19,24 @@
 // Ku^-1 comes from a Cholesky factorisation of Ku + jitter_ku I (jitter_ku = 0 reproduces the reference's inverse; > 0 is the
 // remedy for dense inducing grids where Ku is singular in any precision).
 //
-// Memory: the B x B matrix lives in LDS while it fits (B <= 128), in the caller's workspace (L2-resident) beyond that, so the
-// data-parallel global batch (256, 512) runs through the same code.  Every other array (B x n, n x n, vectors) is in the
+// Memory: tiny batches (B <= 16) keep the B x B matrix in LDS in one 256-thread workgroup; everything else -- the bench batch of 64
+// and the data-parallel global minibatches (256, 512: dp_gain='global') -- takes a second path through the same arithmetic with the
+// matrix in the caller's workspace (L2-resident) (round 2 ran every size through the small-batch code: one 256-thread workgroup walking B unblocked columns with the matrix in L2 --
+// 14 + 40 ms at B = 512): 1024-thread workgroups, a BLOCKED Cholesky whose 16-column panel lives in LDS (the trailing update reads
+// its operands from LDS and touches every matrix element once per panel), and a backward whose two triangular solves L^-T Phi L^-1
+// run as column slabs of the right-hand side on several workgroups per covariate (the columns of a triangular solve are independent).  Every other array (B x n, n x n, vectors) is in the
 // workspace.  Parameter gradients are ADDED straight into the flat fp32 gradient buffer at the parameters' own offsets.
 #include "vg_common.h"
 #include "../../include/vaegam.h"
 
 namespace {
 
-constexpr int GP_T = 256;                  // threads per workgroup
-constexpr int GP_LDS_MAXB = 128;           // B*B*8 <= 128 KiB of the 160 KiB LDS
+constexpr int GP_T = 256;                  // threads per workgroup (B <= GP_LDS_MAXB)
+constexpr int GP_TB = 1024;                // threads per workgroup of the large-batch path
+constexpr int GP_LDS_MAXB = 16;            // up to here the one-workgroup path with the B x B matrix in LDS; beyond it the blocked / slab path, which
+                                           // measured faster from B = 32 on (B = 64: 0.74 -> 0.51 ms forward + backward, 128: 2.6 -> 0.52, 512: 54 -> 3.7)
+constexpr int GP_NB = 16;                  // panel width of the blocked factorisation / block rows of the blocked solves
+constexpr int GP_NBP = GP_NB + 1;          // LDS row pitch of a panel in doubles: odd, so that the rows a wavefront's lanes read fall into different banks
 constexpr int TAB_W = 10;                  // table row: {is_gp, is_hrf, gp_index, off_sa, off_logstd, off_qu_m, off_qu_S, off_logkvar, off_log_ls, 0}
 
 struct GpLayout {                          // workspace of ONE covariate, in doubles
@@ -89,6 +97,124 @@ __device__ void solve_LT_inplace(const double* L, int n, double* X, int nc, int 
     __syncthreads();
 }
 
+// In-place BLOCKED right-looking Cholesky of the lower triangle of m (n x n, row-major, in global memory / L2); the upper triangle is
+// zeroed.  pan: n * GP_NBP doubles of LDS.  Per panel of GP_NB columns: the panel (all rows from its diagonal block down) is copied to
+// LDS and factorised there by the unblocked recurrence (a thread per row, two barriers per column), written back, and the trailing
+// matrix is updated from the LDS copy -- a thread owns 4 x 4 blocks of it: 32 panel values from LDS, 16 elements of m read and
+// written once per panel, 256 fused multiply-adds.
+__device__ void chol_blocked(double* m, int n, double* pan) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int k0 = 0; k0 < n; k0 += GP_NB) {
+        const int nb = min(GP_NB, n - k0), r = n - k0;
+        __syncthreads();
+        for (int t = tid; t < r * GP_NB; t += nt) {
+            const int i = t / GP_NB, j = t % GP_NB;
+            pan[i * GP_NBP + j] = (j < nb) ? m[(long long)(k0 + i) * n + k0 + j] : 0.0;
+        }
+        for (int j = 0; j < nb; ++j) {
+            __syncthreads();
+            const double d = sqrt(pan[j * GP_NBP + j]);     // NaN for a non-positive pivot, as cholesky_ex(check_errors=False)
+            __syncthreads();
+            for (int i = j + tid; i < r; i += nt) pan[i * GP_NBP + j] = (i == j) ? d : pan[i * GP_NBP + j] / d;
+            __syncthreads();
+            for (int i = j + 1 + tid; i < r; i += nt) {
+                const double lij = pan[i * GP_NBP + j];
+                const int tmax = min(i, nb - 1);
+                for (int t = j + 1; t <= tmax; ++t) pan[i * GP_NBP + t] -= lij * pan[t * GP_NBP + j];
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < r * nb; t += nt) {
+            const int i = t / nb, j = t % nb;
+            m[(long long)(k0 + i) * n + k0 + j] = pan[i * GP_NBP + j];
+        }
+        // trailing update: m[i][j] -= sum_t pan[i][t] pan[j][t] for k0+nb <= j <= i < n, in 4 x 4 blocks (bj <= bi)
+        const int r2 = r - nb;
+        if (r2 > 0) {
+            const double* P = pan + nb * GP_NBP;                // panel rows below the diagonal block
+            const int nblk = (r2 + 3) / 4;
+            const long long ntile = (long long)nblk * (nblk + 1) / 2;
+            for (long long t = tid; t < ntile; t += nt) {
+                // t -> (bi, bj), bj <= bi: row bi holds bi + 1 tiles
+                int bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+                while ((long long)(bi + 1) * (bi + 2) / 2 <= t) ++bi;
+                while ((long long)bi * (bi + 1) / 2 > t) --bi;
+                const int bj = (int)(t - (long long)bi * (bi + 1) / 2);
+                double acc[4][4];
+#pragma unroll
+                for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+                    for (int b_ = 0; b_ < 4; ++b_) acc[a_][b_] = 0.0;
+                for (int q = 0; q < nb; ++q) {
+                    double pi[4], pj[4];
+#pragma unroll
+                    for (int a_ = 0; a_ < 4; ++a_) {
+                        pi[a_] = P[min(bi * 4 + a_, r2 - 1) * GP_NBP + q];
+                        pj[a_] = P[min(bj * 4 + a_, r2 - 1) * GP_NBP + q];
+                    }
+#pragma unroll
+                    for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+                        for (int b_ = 0; b_ < 4; ++b_) acc[a_][b_] = fma(pi[a_], pj[b_], acc[a_][b_]);
+                }
+#pragma unroll
+                for (int a_ = 0; a_ < 4; ++a_)
+#pragma unroll
+                    for (int b_ = 0; b_ < 4; ++b_) {
+                        const int i = bi * 4 + a_, j = bj * 4 + b_;
+                        if (i < r2 && j <= i) m[(long long)(k0 + nb + i) * n + k0 + nb + j] -= acc[a_][b_];
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    for (long long t = tid; t < (long long)n * n; t += nt) { const int i = (int)(t / n), k = (int)(t % n); if (k > i) m[t] = 0.0; }
+    __syncthreads();
+}
+
+// One slab of nc right-hand sides of  L^T Y = X  (L lower triangular n x n, X n x n row-major, both in global memory), solved in
+// LDS, blocked.  by_rows = false: the slab is the columns [c0, c0 + nc) of X (Y overwrites them);  by_rows = true: the slab is the
+// ROWS [c0, c0 + nc) of X read as columns (i.e. the slab of X^T), and Y is written back into those rows -- the matrix then holds
+// (L^-T X^T)^T = X L^-1, which is what the second solve of  L^-T Phi L^-1  needs, without a transposition pass.
+// The slab stays in LDS for the whole solve (round-3 first version updated it in global memory: one dependent read-modify-write per
+// element and block row, 0.9 ms per solve at B = 512); block rows of GP_NB from the bottom: the block's rows against the diagonal
+// block of L (a thread per column), then every row above gets  X[r'] -= sum_t L[t][r'] X[t].   lds: n * (GP_NB + nc) doubles.
+__device__ void solve_LT_slab(const double* L, int n, double* X, int c0, int nc, bool by_rows, double* lds) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double* Lb = lds;                                          // [GP_NB][n]: rows of the block, columns 0 .. i0 + nb
+    double* Xs = lds + (size_t)GP_NB * n;                      // [n][nc]: the slab
+    for (long long t = tid; t < (long long)n * nc; t += nt) {
+        if (by_rows) { const int c = (int)(t / n), r = (int)(t % n); Xs[r * nc + c] = X[(long long)(c0 + c) * n + r]; }
+        else { const int r = (int)(t / nc), c = (int)(t % nc); Xs[r * nc + c] = X[(long long)r * n + c0 + c]; }
+    }
+    for (int i0 = ((n - 1) / GP_NB) * GP_NB; i0 >= 0; i0 -= GP_NB) {
+        const int nb = min(GP_NB, n - i0);
+        __syncthreads();
+        for (int t = tid; t < nb * (i0 + nb); t += nt) { const int r = t / (i0 + nb), c = t % (i0 + nb); Lb[r * n + c] = L[(long long)(i0 + r) * n + c]; }
+        __syncthreads();
+        for (int c = tid; c < nc; c += nt) {                   // the block's own rows: back substitution, one column per thread
+            for (int r = nb - 1; r >= 0; --r) {
+                double v = Xs[(i0 + r) * nc + c];
+                for (int q = r + 1; q < nb; ++q) v -= Lb[q * n + i0 + r] * Xs[(i0 + q) * nc + c];
+                Xs[(i0 + r) * nc + c] = v / Lb[r * n + i0 + r];
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < i0 * nc; t += nt) {
+            const int r = t / nc, c = t % nc;
+            double v = 0.0;
+            for (int q = 0; q < nb; ++q) v = fma(Lb[q * n + r], Xs[(i0 + q) * nc + c], v);
+            Xs[r * nc + c] -= v;
+        }
+    }
+    __syncthreads();
+    for (long long t = tid; t < (long long)n * nc; t += nt) {
+        if (by_rows) { const int c = (int)(t / n), r = (int)(t % n); X[(long long)(c0 + c) * n + r] = Xs[r * nc + c]; }
+        else { const int r = (int)(t / nc), c = (int)(t % nc); X[(long long)r * n + c0 + c] = Xs[r * nc + c]; }
+    }
+    __syncthreads();
+}
+
 // inv <- (L L^T)^-1 for lower-triangular L (n x n); tmp: n x n scratch (receives L^-1)
 __device__ void spd_inverse_from_chol(const double* L, int n, double* tmp, double* inv) {
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -121,13 +247,13 @@ __device__ __forceinline__ double knu_dist(double xu0, double xb, int k, double 
     return round32 ? (double)(float)d : d;
 }
 
-// block-wide sum of one double per thread (fixed order): red = GP_T doubles of LDS
+// block-wide sum of one double per thread (fixed order): red = blockDim.x (a power of two) doubles of LDS
 __device__ double block_sum(double v, double* red) {
     const int tid = threadIdx.x;
     __syncthreads();
     red[tid] = v;
     __syncthreads();
-    for (int s = GP_T / 2; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    for (int s = (int)blockDim.x / 2; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
     const double r = red[0];
     __syncthreads();
     return r;
@@ -141,17 +267,18 @@ struct GainArgs {
 };
 
 // ------------------------------------------------------------------------------------------------ forward
-__global__ void __launch_bounds__(GP_T)
+template <int T>
+__global__ void __launch_bounds__(T)
 gain_fwd_k(GainArgs a, float* __restrict__ task_var, double* __restrict__ kl_part,
            double* __restrict__ o_bm, double* __restrict__ o_bc, double* __restrict__ o_fb, double* __restrict__ o_sg) {
     VG_DYN_SMEM(double, lds);
-    double* red = lds;                                         // GP_T doubles
+    double* red = lds;                                         // T doubles
     const int c = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int B = a.B, n = a.n;
     const GpLayout w = gp_layout(B, n);
     double* W = a.ws + (size_t)c * w.total;
     const bool in_lds = B <= GP_LDS_MAXB;
-    double* Cm = in_lds ? lds + GP_T : W + w.Lc;               // the B x B matrix being built / factorised
+    double* Cm = in_lds ? lds + T : W + w.Lc;                  // the B x B matrix being built / factorised
     const long long* tb = a.tab + (size_t)c * TAB_W;
     const bool is_gp = tb[0] != 0, is_hrf = tb[1] != 0;
     const int gk = (int)tb[2];
@@ -248,17 +375,29 @@ gain_fwd_k(GainArgs a, float* __restrict__ task_var, double* __restrict__ kl_par
         if (o_bm) for (int b = tid; b < B; b += nt) o_bm[(size_t)c * B + b] = bm[b];
     }
     __syncthreads();
-    chol_inplace(Cm, B);
+    if (in_lds) chol_inplace(Cm, B);
+    else chol_blocked(Cm, B, lds + T);                         // large batches: 16-column panels in LDS
     if (in_lds) {
         double* Lc = W + w.Lc;
         for (long long t = tid; t < (long long)B * B; t += nt) Lc[t] = Cm[t];
     }
     // gain = beta_mean + L eps, then the HRF along the batch index
     double* tv = W + w.v1;
-    for (int b = tid; b < B; b += nt) {
-        double s = bm[b];
-        for (int j = 0; j <= b; ++j) s += Cm[(long long)b * B + j] * e[j];
-        tv[b] = s;
+    if (in_lds) {
+        for (int b = tid; b < B; b += nt) {
+            double s = bm[b];
+            for (int j = 0; j <= b; ++j) s += Cm[(long long)b * B + j] * e[j];
+            tv[b] = s;
+        }
+    } else {
+        // the factor is in global memory: a WAVEFRONT per row (lanes along the row: coalesced), fixed-order shuffle reduction
+        const int lane = tid % VG_WAVE, wv = tid / VG_WAVE, nwv = nt / VG_WAVE;
+        for (int b = wv; b < B; b += nwv) {
+            double s = 0.0;
+            for (int j = lane; j <= b; j += VG_WAVE) s += Cm[(long long)b * B + j] * e[j];
+            for (int off = VG_WAVE / 2; off > 0; off >>= 1) s += __shfl_down(s, off);
+            if (lane == 0) tv[b] = bm[b] + s;
+        }
     }
     __syncthreads();
     for (int b = tid; b < B; b += nt) {
@@ -287,7 +426,10 @@ __global__ void gain_kl_sum_k(const double* __restrict__ kl_part, int C, float* 
 // ------------------------------------------------------------------------------------------------ backward
 // g_tv [C][B]: d loss / d gain (fp32),  g_kl [1]: d loss / d (sum of the KL terms).  Parameter gradients are added into G32
 // (the flat fp32 gradient buffer, same offsets as P).
-__global__ void __launch_bounds__(GP_T)
+// PHASE 0: the whole backward (B x B matrix in LDS).  Large batches: PHASE 1 = up to Phi (left in the workspace), then the two
+// triangular solves as slab launches (gain_trsm_k), PHASE 2 = everything behind them.
+template <int T, int PHASE>
+__global__ void __launch_bounds__(T)
 gain_bwd_k(GainArgs a, const float* __restrict__ g_tv, const float* __restrict__ g_kl, float* __restrict__ G32) {
     VG_DYN_SMEM(double, lds);
     double* red = lds;
@@ -296,7 +438,7 @@ gain_bwd_k(GainArgs a, const float* __restrict__ g_tv, const float* __restrict__
     const GpLayout w = gp_layout(B, n);
     double* W = a.ws + (size_t)c * w.total;
     const bool in_lds = B <= GP_LDS_MAXB;
-    double* Gm = in_lds ? lds + GP_T : W + w.G;                // d loss / d beta_cov, built in place
+    double* Gm = in_lds ? lds + T : W + w.G;                   // d loss / d beta_cov, built in place
     const long long* tb = a.tab + (size_t)c * TAB_W;
     const bool is_gp = tb[0] != 0, is_hrf = tb[1] != 0;
     const double* x = W + w.x; const double* e = W + w.e; const double* Lc = W + w.Lc;
@@ -304,6 +446,7 @@ gain_bwd_k(GainArgs a, const float* __restrict__ g_tv, const float* __restrict__
     const double sa = sc[0], std_ = sc[1], kvar = sc[2], ls = sc[3], step = sc[4];
     const double gkl = (double)g_kl[0];
     double* g = W + w.v1; double* u = W + w.v2; double* gin = W + w.v3;
+    if (PHASE != 2) {
     // HRF transposed: g[i] = sum_t hk[t] gin[i + t]
     for (int b = tid; b < B; b += nt) gin[b] = (double)g_tv[(size_t)c * B + b];
     __syncthreads();
@@ -328,6 +471,7 @@ gain_bwd_k(GainArgs a, const float* __restrict__ g_tv, const float* __restrict__
         Gm[t] = (j < i) ? u[i] * e[j] : (j == i ? 0.5 * u[i] * e[i] : 0.0);
     }
     __syncthreads();
+    if (PHASE == 1) return;
     // S = L^-T Phi L^-1:  X = L^-T Phi;  S^T = L^-T X^T;  d beta_cov = (S + S^T) / 2
     solve_LT_inplace(Lc, B, Gm, B, B);
     for (long long t = tid; t < (long long)B * B; t += nt) {   // transpose in place (pairwise swap)
@@ -336,6 +480,7 @@ gain_bwd_k(GainArgs a, const float* __restrict__ g_tv, const float* __restrict__
     }
     __syncthreads();
     solve_LT_inplace(Lc, B, Gm, B, B);
+    }                                                          // (PHASE 2 starts here: Gm = L^-T Phi L^-1 from the slab launches)
     for (long long t = tid; t < (long long)B * B; t += nt) {
         const int i = (int)(t / B), j = (int)(t % B);
         if (j < i) { const double s = 0.5 * (Gm[(long long)i * B + j] + Gm[(long long)j * B + i]); Gm[(long long)i * B + j] = s; Gm[(long long)j * B + i] = s; }
@@ -361,25 +506,53 @@ gain_bwd_k(GainArgs a, const float* __restrict__ g_tv, const float* __restrict__
     const double isl = 1.0 / sqrt(2.0) / ls;
     const float* xu = a.xu + (size_t)tb[2] * n;
     const double xu0 = (double)xu[0];
-    // G2 = dSigma A  (dSigma symmetric)
-    for (int t = tid; t < B * n; t += nt) {
-        const int b = t / n, k = t % n;
-        double s = 0.0;
-        for (int j = 0; j < B; ++j) s += Gm[(long long)b * B + j] * A[j * n + k];
-        G2[t] = s;
-    }
-    __syncthreads();
-    // dM = A^T G2 ; dm = A^T g (+ KL) ; dA = g m^T + G2 (M + M^T)
-    for (int t = tid; t < n * n; t += nt) {
-        const int p = t / n, q = t % n;
-        double s = 0.0;
-        for (int b = 0; b < B; ++b) s += A[b * n + p] * G2[b * n + q];
-        gM[t] = s;
-    }
-    for (int k = tid; k < n; k += nt) {
-        double s = 0.0;
-        for (int b = 0; b < B; ++b) s += A[b * n + k] * g[b];
-        G32[tb[5] + k] += (float)(s + gkl * (double)qm[k] / a.prior_var);
+    // G2 = dSigma A  (dSigma symmetric);  dM = A^T G2 ; dm = A^T g (+ KL)
+    if (in_lds) {
+        for (int t = tid; t < B * n; t += nt) {
+            const int b = t / n, k = t % n;
+            double s = 0.0;
+            for (int j = 0; j < B; ++j) s += Gm[(long long)b * B + j] * A[j * n + k];
+            G2[t] = s;
+        }
+        __syncthreads();
+        for (int t = tid; t < n * n; t += nt) {
+            const int p = t / n, q = t % n;
+            double s = 0.0;
+            for (int b = 0; b < B; ++b) s += A[b * n + p] * G2[b * n + q];
+            gM[t] = s;
+        }
+        for (int k = tid; k < n; k += nt) {
+            double s = 0.0;
+            for (int b = 0; b < B; ++b) s += A[b * n + k] * g[b];
+            G32[tb[5] + k] += (float)(s + gkl * (double)qm[k] / a.prior_var);
+        }
+    } else {
+        // large batches: the sums run over B = 256..1000 terms held in global memory -- a WAVEFRONT per output, lanes along the sum
+        // (coalesced), fixed-order shuffle reduction (a thread per output walked them one dependent load at a time: with n*n or n
+        // outputs only a few dozen threads were busy for hundreds of microseconds)
+        const int lane = tid % VG_WAVE, wv = tid / VG_WAVE, nwv = nt / VG_WAVE;
+        auto wsum = [&](double v) { for (int off = VG_WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off); return v; };
+        for (int t = wv; t < B * n; t += nwv) {
+            const int b = t / n, k = t % n;
+            double s = 0.0;
+            for (int j = lane; j < B; j += VG_WAVE) s += Gm[(long long)b * B + j] * A[j * n + k];
+            s = wsum(s);
+            if (lane == 0) G2[t] = s;
+        }
+        __syncthreads();
+        for (int t = wv; t < n * n; t += nwv) {
+            const int p = t / n, q = t % n;
+            double s = 0.0;
+            for (int b = lane; b < B; b += VG_WAVE) s += A[b * n + p] * G2[b * n + q];
+            s = wsum(s);
+            if (lane == 0) gM[t] = s;
+        }
+        for (int k = wv; k < n; k += nwv) {
+            double s = 0.0;
+            for (int b = lane; b < B; b += VG_WAVE) s += A[b * n + k] * g[b];
+            s = wsum(s);
+            if (lane == 0) G32[tb[5] + k] += (float)(s + gkl * (double)qm[k] / a.prior_var);
+        }
     }
     for (int t = tid; t < B * n; t += nt) {
         const int b = t / n, k = t % n;
@@ -415,13 +588,24 @@ gain_bwd_k(GainArgs a, const float* __restrict__ g_tv, const float* __restrict__
         for (int j = 0; j < n; ++j) s += gA[b * n + j] * kinv[k * n + j];
         gKnuT[t] = s;
     }
-    for (int t = tid; t < n * n; t += nt) {
-        const int p = t / n, q = t % n;
-        double s = 0.0;
-        for (int b = 0; b < B; ++b) {
-            s += kern1(knu_dist(xu0, x[b], p, step, a.jitter_ku == 0.0), isl) * gA[b * n + q];
+    if (in_lds) {
+        for (int t = tid; t < n * n; t += nt) {
+            const int p = t / n, q = t % n;
+            double s = 0.0;
+            for (int b = 0; b < B; ++b) {
+                s += kern1(knu_dist(xu0, x[b], p, step, a.jitter_ku == 0.0), isl) * gA[b * n + q];
+            }
+            gKinv[t] = s;
         }
-        gKinv[t] = s;
+    } else {
+        const int lane = tid % VG_WAVE, wv = tid / VG_WAVE, nwv = nt / VG_WAVE;
+        for (int t = wv; t < n * n; t += nwv) {
+            const int p = t / n, q = t % n;
+            double s = 0.0;
+            for (int b = lane; b < B; b += VG_WAVE) s += kern1(knu_dist(xu0, x[b], p, step, a.jitter_ku == 0.0), isl) * gA[b * n + q];
+            for (int off = VG_WAVE / 2; off > 0; off >>= 1) s += __shfl_down(s, off);
+            if (lane == 0) gKinv[t] = s;
+        }
     }
     __syncthreads();
     for (int t = tid; t < B * n; t += nt) {
@@ -453,6 +637,22 @@ gain_bwd_k(GainArgs a, const float* __restrict__ g_tv, const float* __restrict__
     }
 }
 
+// right-hand sides per slab of a large-batch solve: the slab (B x nc) and a block row of L (GP_NB x B) share the 160 KB of LDS
+__host__ __device__ inline int gp_slab_cols(int B) { return B <= 608 ? 16 : (B <= 832 ? 8 : 4); }
+
+// large batches: one slab of  L^-T (.)  on the B x B matrix at w.G (L at w.Lc); grid = C * ceil(B / gp_slab_cols(B)) workgroups
+__global__ void __launch_bounds__(GP_TB)
+gain_trsm_k(GainArgs a, int by_rows) {
+    VG_DYN_SMEM(double, lds);
+    const int B = a.B;
+    const int per = gp_slab_cols(B), nsl = (B + per - 1) / per;
+    const int c = blockIdx.x / nsl, sl = blockIdx.x % nsl;
+    const GpLayout w = gp_layout(B, a.n);
+    double* W = a.ws + (size_t)c * w.total;
+    const int c0 = sl * per, nc = min(per, B - c0);
+    solve_LT_slab(W + w.Lc, B, W + w.G, c0, nc, by_rows != 0, lds);
+}
+
 GainArgs mk_args(const vg_gain_desc* d, const int64_t* table, const float* params, const float* xu, const float* cov, int64_t ldc,
                  const float* eps, const double* hrf, double* ws) {
     GainArgs a;
@@ -462,10 +662,12 @@ GainArgs mk_args(const vg_gain_desc* d, const int64_t* table, const float* param
     return a;
 }
 
-size_t lds_bytes(int B) { return (size_t)(GP_T + (B <= GP_LDS_MAXB ? (size_t)B * B : 0)) * sizeof(double); }
+size_t lds_bytes(int B) { return (size_t)(GP_T + (size_t)B * B) * sizeof(double); }                       // B <= GP_LDS_MAXB
+size_t lds_bytes_big(int B) { return (size_t)(GP_TB + (size_t)B * GP_NBP) * sizeof(double); }             // reduction scratch + one factorisation panel
+size_t lds_bytes_trsm(int B) { return (size_t)B * (GP_NB + gp_slab_cols(B)) * sizeof(double); }
 
 int check(const vg_gain_desc* d, const char* who) {
-    if (!d || d->C <= 0 || d->B <= 0 || d->n < 2 || d->n > 128 || d->B > 4096 || d->hrf_taps < 0 || !(d->prior_var > 0)) {
+    if (!d || d->C <= 0 || d->B <= 0 || d->n < 2 || d->n > 128 || d->B > 1024 || d->hrf_taps < 0 || !(d->prior_var > 0)) {
         vg_set_error("%s: bad descriptor", who); return VG_ERR_ARG;
     }
     return VG_OK;
@@ -493,7 +695,8 @@ extern "C" int vg_gp_gain_fwd(const vg_gain_desc* d, const int64_t* table, const
     double* wsd = (double*)ws;
     double* kl_part = wsd + (size_t)w.total * d->C;
     GainArgs a = mk_args(d, table, params, xu, covariates, ld_cov, eps_beta, hrf_taps, wsd);
-    vg_launch(gain_fwd_k, dim3(d->C), dim3(GP_T), lds_bytes(d->B), s, a, task_var, kl_part, beta_mean, beta_cov, f_bar, Sigma);
+    if (d->B <= GP_LDS_MAXB) vg_launch(gain_fwd_k<GP_T>, dim3(d->C), dim3(GP_T), lds_bytes(d->B), s, a, task_var, kl_part, beta_mean, beta_cov, f_bar, Sigma);
+    else vg_launch(gain_fwd_k<GP_TB>, dim3(d->C), dim3(GP_TB), lds_bytes_big(d->B), s, a, task_var, kl_part, beta_mean, beta_cov, f_bar, Sigma);
     rc = vg_check_launch("gp_gain_fwd");
     if (rc) return rc;
     vg_launch(gain_kl_sum_k, dim3(1), dim3(64), 0, s, (const double*)kl_part, (int)d->C, gp_kl);
@@ -509,6 +712,16 @@ extern "C" int vg_gp_gain_bwd(const vg_gain_desc* d, const int64_t* table, const
         vg_set_error("vg_gp_gain_bwd: null argument"); return VG_ERR_ARG;
     }
     GainArgs a = mk_args(d, table, params, xu, covariates, ld_cov, eps_beta, hrf_taps, (double*)ws);
-    vg_launch(gain_bwd_k, dim3(d->C), dim3(GP_T), lds_bytes(d->B), (hipStream_t)stream, a, g_task_var, g_gp_kl, flat_grads);
-    return vg_check_launch("gp_gain_bwd");
+    hipStream_t s = (hipStream_t)stream;
+    if (d->B <= GP_LDS_MAXB) {
+        vg_launch(gain_bwd_k<GP_T, 0>, dim3(d->C), dim3(GP_T), lds_bytes(d->B), s, a, g_task_var, g_gp_kl, flat_grads);
+        return vg_check_launch("gp_gain_bwd");
+    }
+    // large batches: Phi -> L^-T Phi -> (.) L^-1 -> the rest; each solve as slabs of 16 right-hand sides, a workgroup each
+    vg_launch(gain_bwd_k<GP_TB, 1>, dim3(d->C), dim3(GP_TB), lds_bytes_big(d->B), s, a, g_task_var, g_gp_kl, flat_grads);
+    const int nsl = (d->B + gp_slab_cols(d->B) - 1) / gp_slab_cols(d->B);
+    vg_launch(gain_trsm_k, dim3(d->C * nsl), dim3(GP_TB), lds_bytes_trsm(d->B), s, a, 0);      // X = L^-T Phi          (column slabs)
+    vg_launch(gain_trsm_k, dim3(d->C * nsl), dim3(GP_TB), lds_bytes_trsm(d->B), s, a, 1);      // X L^-1 = (L^-T X^T)^T (row slabs, in place)
+    vg_launch(gain_bwd_k<GP_TB, 2>, dim3(d->C), dim3(GP_TB), lds_bytes_big(d->B), s, a, g_task_var, g_gp_kl, flat_grads);
+    return vg_check_launch("gp_gain_bwd (large batch)");
 }

@@ -74,7 +74,7 @@ def main(argv=None):
     model = vae_reg.VAE(num_inducing_pts=args.num_inducing_pts, gp_kl_scale=args.gp_kl_scale,
                         glm_reg_scale=args.glm_reg_scale, glm_maps=args.glm_maps, save_dir=args.save_dir,
                         csv_files=[args.train_csv, args.test_csv], neural_covariates=args.neural_covariates,
-                        data_parallel=dp, dp_gain=os.environ.get('VG_DP_GAIN', 'local'), gp_jitter=args.gp_jitter)
+                        data_parallel=dp, dp_gain=os.environ.get('VG_DP_GAIN', 'global'), gp_jitter=args.gp_jitter)
     if args.from_ckpt:
         assert os.path.exists(args.ckpt_path), 'Oops, looks like ckpt file given does NOT exist!'
         print('=' * 40)

@@ -87,7 +87,7 @@ class VAE(nn.Module):
     def __init__(self, nf=8, save_dir='', lr=1e-3, num_covariates=8, num_latents=32, device_name="auto",
                  num_inducing_pts=6, gp_kl_scale=10.0, glm_maps='', glm_reg_scale=1.0, csv_files='',
                  neural_covariates=True, *, img_shape=IMG_SHAPE, xu_ranges=None, tensorboard=False,
-                 data_parallel=None, gp_jitter=0.0, dp_gain='local'):
+                 data_parallel=None, gp_jitter=0.0, dp_gain='global'):
         """Arguments up to `neural_covariates` are the reference's (vae_reg_GP.py:36-37).
         Keyword-only extensions: `img_shape` (41x49x35 or 82x98x70), `xu_ranges` (inducing-point
         ranges given directly instead of read from `csv_files`), `tensorboard` (off by default),
@@ -95,14 +95,16 @@ class VAE(nn.Module):
         inducing-point kernel matrix Ku, gp.py:104-107; > 0: Ku + gp_jitter*I on the unit-variance scale, i.e. the
         inducing prior k_var*(Ku + jitter I), factorised by Cholesky -- needed where the inducing grid is dense against the
         length scale and Ku is singular in any precision, e.g. 64 points).  `dp_gain` (data parallel only):
-        'global' = the gains of the whole global minibatch are drawn jointly on every rank from the dense Bg x Bg gain covariance
-        (vae_reg_GP.py:363-369): exactly the one-process global-batch step, but O(Bg^2..3) serial work per rank.
+        'global' (default) = the gains of the whole global minibatch are drawn jointly on every rank from the dense Bg x Bg gain
+        covariance (vae_reg_GP.py:363-369; covariates all-gathered, identical seeded noise, own columns kept): exactly the one-process
+        global-batch step.  Its O(Bg^3) Cholesky / triangular solves run blocked on the matrix cores' neighbours (vg_gp.hip, large-batch
+        path): 0.5 + 0.7 ms at Bg = 256, 1.8 + 1.9 ms at 512, on a side stream beside the conv stacks.
         'local' = every rank draws the gains of ITS slice from that slice's own B x B block -- the block-DIAGONAL approximation of
         the joint draw: gains of volumes on different ranks are drawn independently (their covariance through the GP is dropped),
         every volume's own marginal N(beta_mean_b, Sigma_bb) is unchanged; the HRF of the neural covariates still runs along the
-        GLOBAL batch index across the slices (ops.HrfAcrossRanks).  This is a different stochastic estimate of the loss than the
-        1-rank global-batch step (same expectation for the non-HRF covariates; for an HRF covariate the 14 volumes behind a slice
-        boundary lose the cross-slice covariance terms of their convolved gain); its cost does not grow with the number of ranks.
+        GLOBAL batch index across the slices (ops.HrfAcrossRanks).  A different stochastic estimate of the loss than the 1-rank
+        global-batch step (same expectation for the non-HRF covariates; for an HRF covariate the 14 volumes behind a slice boundary
+        lose the cross-slice covariance terms of their convolved gain); kept as an option: its cost does not grow with the ranks.
         `glm_maps` may be a CSV path
         (reference) or an array of shape (V, C+1) whose column 0 is the CSV index column."""
         super(VAE, self).__init__()
