@@ -756,12 +756,18 @@ struct WgradRowsParams {
     int ones_row;               // 1: MFMA row CB carries a constant-one position channel -> per-tap sums of the window tensor
 };
 
-template <int CA, int TC, int KD, int KH, int KW, int S, bool PAD, bool PA, int UG, bool RES, bool GRP = false>
+// DSH (stride-2 layers with 8 position channels, KD >= 2*S): the 8 idle MFMA rows carry the SAME channels one position plane further on.
+// With the window operand restricted to the taps kd' in [S, KD), row (h = 0, cb) accumulates dw[cb][.][kd'] and row (h = 1, cb) -- whose
+// position is one plane = S window planes ahead -- accumulates dw[cb][.][kd' - S]: together every kd in [0, KD), from (KD-S)*KH*KW instead
+// of KD*KH*KW window taps (convt4: 27 instead of 45 = 2 instead of 3 matrix instructions per k-step and channel; the 4x4x4 layer of the
+// 82x98x70 geometry: 32 instead of 64 = 2 instead of 4).  The position planes of a tile start at -1 (row h = 1 covers plane 0 there).
+template <int CA, int TC, int KD, int KH, int KW, int S, bool PAD, bool PA, int UG, bool RES, bool GRP = false, bool DSH = false>
 __global__ void __launch_bounds__(256, (CA * TC >= 32 ? 2 : CA * TC >= 16 ? VG_WG_MINB : 1))         // 32 accumulator tiles: keep two waves per SIMD (<= 256 registers)
 wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ in_scale,
              const float* __restrict__ in_shift, float* __restrict__ ws, WgradRowsParams p) {
     VG_DYN_SMEM(float, lds);
     constexpr int KVOL = KD * KH * KW;
+    constexpr int KVW = DSH ? (KD - S) * KH * KW : KVOL;               // window taps the matrix columns enumerate
     constexpr int NT = CA * TC;
     const vg_wgrad_desc& d = p.d;
     const int CB = d.CB;
@@ -776,8 +782,8 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
 #pragma unroll
     for (int t = 0; t < TC; ++t) {
         const int tap = t * 16 + cbl;
-        const bool ok = tap < KVOL;
-        tkd[t] = ok ? tap / (KH * KW) : 0; tkh[t] = ok ? (tap / KW) % KH : 0; tkw[t] = ok ? tap % KW : 0;
+        const bool ok = tap < KVW;
+        tkd[t] = ok ? tap / (KH * KW) : 0; tkh[t] = ok ? (tap / KW) % KH : 0; tkw[t] = ok ? tap % KW : 0;     // DSH: tkd counts from kd' = S
         colOff[t] = tkd[t] * p.apl + tkh[t] * d.AW + tkw[t];
     }
     vg_f32x4 acc[NT];
@@ -788,12 +794,21 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
     const float lo_a = rl_a ? 0.f : -__builtin_inff(), lo_b = rl_b ? 0.f : -__builtin_inff();
     const int ksteps = (d.PW + 3) / 4;
     const int aplane = d.AH * d.AW, bplane = d.PH * d.PW;
-    const bool cb_ok = cbl < CB;
-    const float* bchan = btile + min(cbl, CB - 1) * p.bch + kq;
+    const bool cb_ok = cbl < (DSH ? 2 * CB : CB);
+    // DSH: lanes CB .. 2CB-1 read the same channels one position plane (TPH*PW floats of the tile) further on
+    const float* bchan = btile + (DSH ? (cbl % CB) : min(cbl, CB - 1)) * p.bch + ((DSH && cbl >= CB) ? p.TPH * d.PW : 0) + kq;
     __syncthreads();
 
     const int CBW = CB + (GRP ? 1 : 0);                                  // rows of dw written out (grouped: + the ones row)
     const int ncol_o = CA * KVOL;
+    // matrix row cbr, window tap -> (row of dw, tap of dw), or -1: plain = (cbr, tap); DSH: see above
+    auto out_index = [&](int cbr, int tap, int ca) -> long long {
+        if (!DSH) return (cbr < CBW && tap < KVOL) ? (long long)cbr * ncol_o + ca * KVOL + tap : -1;
+        if (cbr >= 2 * CB || tap >= KVW) return -1;
+        const int h = cbr / CB, cb = cbr % CB, kdw = tap / (KH * KW), rest = tap % (KH * KW);
+        if (h == 1 && kdw >= S) return -1;                                // a duplicate of row h = 0's kd = kdw
+        return (long long)cb * ncol_o + ca * KVOL + (h == 0 ? kdw + S : kdw) * (KH * KW) + rest;
+    };
     // ---- close a slab: the block's (or, small grids, each wave's) partial dw -> workspace
     auto write_out = [&](int slab) {
         if (p.wave_slabs) {
@@ -803,8 +818,10 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
             for (int t = 0; t < NT; ++t) {
                 const int ca = t / TC, tap = (t % TC) * 16 + tapl;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (cb0 + r < CBW && tap < KVOL) out[(size_t)(cb0 + r) * ncol_o + ca * KVOL + tap] = acc[t].v[r];
+                for (int r = 0; r < 4; ++r) {
+                    const long long oi = out_index(cb0 + r, tap, ca);
+                    if (oi >= 0) out[oi] = acc[t].v[r];
+                }
                 VG_WG_FENCE();                      // one tile at a time: otherwise all NT*4 accumulators are copied to VGPRs up front
             }
             return;
@@ -830,7 +847,8 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
             const int l = i % VG_WAVE; const int r = (i / VG_WAVE) % 4; const int t = i / (4 * VG_WAVE);
             const int ca = t / TC, tap = (t % TC) * 16 + (l & 15);
             const int cb = (l >> 4) * 4 + r;
-            if (cb < CBW && tap < KVOL) out[(size_t)cb * ncol_o + ca * KVOL + tap] = red[i];
+            const long long oi = out_index(cb, tap, ca);
+            if (oi >= 0) out[oi] = red[i];
         }
     };
     // plain mode: items blockIdx.x, +gridDim.x, ...   grouped mode: the grid is split evenly over the batch-norm groups (ipb = blocks per
@@ -846,10 +864,10 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
 #endif
     for (int item = it0; item < it1; item += it_step) {
         const int n = item / (p.pdblocks * p.nph); const int rem = item % (p.pdblocks * p.nph);
-        const int pd0 = (rem / p.nph) * p.TPD, ph0 = (rem % p.nph) * p.TPH;
+        const int pd0 = (rem / p.nph) * p.TPD - (DSH ? 1 : 0), ph0 = (rem % p.nph) * p.TPH;
         const int nrow = min(p.TPH, d.PH - ph0), ndz = min(p.TPD, d.PD - pd0);
         const int g = (in_scale != nullptr) ? n / d.per_group : 0;
-        const int ap0 = pd0 * S - d.pad_d, ih0 = ph0 * S - d.pad_h;
+        const int ap0 = pd0 * S - d.pad_d + (DSH ? S : 0), ih0 = ph0 * S - d.pad_h;
         const int pl_lo = max(ap0, 0), pl_hi = min(ap0 + p.LD, d.AD);
         const int r_lo = max(ih0, 0), r_hi = min(ih0 + p.AR, d.AH);
         const int npl = max(pl_hi - pl_lo, 0);
@@ -857,7 +875,7 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
         const int adst = p.a_front + (pl_lo - ap0) * p.apl + (r_lo - ih0) * d.AW;
         const float* abase = a + (((size_t)n * CA * d.AD + pl_lo) * d.AH + r_lo) * d.AW;
         float bsc = cb_ok ? 1.f : 0.f, bsh = 0.f;                        // lanes without a b channel contribute zeros
-        if (!PA && in_scale && cb_ok) { bsc = in_scale[g * CB + cbl]; bsh = in_shift[g * CB + cbl]; }
+        if (!PA && in_scale && cb_ok) { bsc = in_scale[g * CB + (DSH ? cbl % CB : cbl)]; bsh = in_shift[g * CB + (DSH ? cbl % CB : cbl)]; }
         if (GRP && cbl == CB) bsh = 1.f;                                 // ones row (bsc stays 0: the lane reads channel CB-1's finite data)
         VG_WS_ADD(0);                                                     // item set-up
         __syncthreads();                                                  // previous item's tiles fully consumed
@@ -881,12 +899,14 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
         {
             const int nb = nrow * d.PW;
             const size_t bch_g = (size_t)d.PD * bplane;
-            const float* src_c = b + ((size_t)n * CB + wave) * bch_g + (size_t)pd0 * bplane + (size_t)ph0 * d.PW;
+            const float* src_c = b + ((size_t)n * CB + wave) * bch_g + (long long)pd0 * bplane + (size_t)ph0 * d.PW;     // (DSH: pd0 may be -1; such planes are not read)
             float* dst_c = btile + wave * p.bch;
+            const int ndzs = DSH ? ndz + 1 : ndz;                         // DSH: + the plane behind the tile (rows h = 1 of its last plane)
             for (int c = wave; c < CB; c += 4, src_c += 4 * bch_g, dst_c += 4 * p.bch) {
                 const float* src = src_c; float* dst = dst_c;
-                for (int dz = 0; dz < ndz; ++dz, src += bplane, dst += p.TPH * d.PW) {
-                    vg_dma_span(src + lane, dst, nb, lane);
+                for (int dz = 0; dz < ndzs; ++dz, src += bplane, dst += p.TPH * d.PW) {
+                    if (!DSH || (pd0 + dz >= 0 && pd0 + dz < d.PD)) vg_dma_span(src + lane, dst, nb, lane);
+                    else for (int o = lane; o < nb; o += VG_WAVE) dst[o] = 0.f;      // a plane outside the tensor: its positions contribute nothing
                 }
             }
         }
@@ -895,6 +915,16 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
         VG_WS_ADD(3);                                                     // copy wait
         __syncthreads();
         VG_WS_ADD(1);
+        // DSH: a position plane outside the tensor (plane -1 of rows h = 0, plane PD of rows h = 1) contributes exactly nothing, whatever
+        // the prologue's shift: its lanes' scale and shift are zeroed per plane (the tile holds zeros there)
+        float bscz = bsc, bshz = bsh;
+        auto plane_factors = [&](int dz) {
+            if (DSH) {
+                const int pl = pd0 + dz + (cbl >= CB ? 1 : 0);
+                const bool v = pl >= 0 && pl < d.PD;
+                bscz = v ? bsc : 0.f; bshz = v ? bsh : 0.f;
+            }
+        };
         // one position row against one `a` channel: UG k-steps per iteration, all operand reads first, then the matrix
         // instructions.  ONE branch-free loop whose trip count is rounded up to UG (surplus k-steps have px >= PW: their A
         // operand is zeroed, their reads stay inside the tiles' slack); only the LAST block can hold such positions and it
@@ -914,7 +944,7 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
 #pragma unroll
                 for (int u = 0; u < UG; ++u) {
                     const int px = (ks + u) * 4 + kq;
-                    float a_ = fmaf(vg_max(av[u], lo_b), bsc, bsh);               // PA: lo_b = -inf, bsc = 1 (0 for idle lanes), bsh = 0
+                    float a_ = fmaf(vg_max(av[u], lo_b), bscz, bshz);             // PA: lo_b = -inf, bsc = 1 (0 for idle lanes), bsh = 0
                     if (MASKED) a_ = px < d.PW ? a_ : 0.f;
 #pragma unroll
                     for (int t = 0; t < TC; ++t) {
@@ -950,6 +980,7 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
             }
             for (int dz = 0; dz < ndz; ++dz)
             for (int py = (wave - dz * nrow) & 3; py < nrow; py += 4) {
+                plane_factors(dz);
                 const float* bp = bchan + (dz * p.TPH + py) * d.PW;
                 const float* ap0_ = lds + p.a_front + (dz * S) * p.apl + (py * S) * d.AW + kq * S - d.pad_w;
                 bool okdh[TC];
@@ -970,6 +1001,7 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
                 // rows of the tile dealt round-robin over the 4 waves ((plane, row) wave-uniform: scalars, no division)
                 for (int dz = 0; dz < ndz; ++dz)
                 for (int py = (wave - dz * nrow) & 3; py < nrow; py += 4) {
+                    plane_factors(dz);
                     const float* bp = bchan + (dz * p.TPH + py) * d.PW;
                     const float* ap = cur + p.a_front + (dz * S) * p.apl + (py * S) * d.AW + kq * S - d.pad_w;
                     bool okdh[TC];
@@ -1017,13 +1049,16 @@ slab_sum_groups_k(const float* __restrict__ ws, int spg, int len, float* __restr
 }
 
 // returns -1 when the geometry does not fit (caller falls back)
-template <int CA, int TC, int KD, int KH, int KW, int S, bool PAD>
+template <int CA, int TC, int KD, int KH, int KW, int S, bool PAD, bool DSH = false>
 int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const float* in_scale, const float* in_shift,
                 float* ws, float* dw, hipStream_t s, int64_t* ws_bytes_only, int accumulate, int grouped = 0) {
     constexpr int KVOL = KD * KH * KW;
     constexpr int NT = CA * TC;
+    constexpr int KDW = DSH ? KD - S : KD;                              // window planes a position touches (DSH: taps kd' in [S, KD) only)
     const bool padded = d->pad_d || d->pad_h || d->pad_w;
     if (padded != PAD || d->CA != CA || d->CB > 16) return -1;
+    if (DSH && (2 * d->CB > 16 || grouped || KD < 2 * S)) return -1;       // (never on in_scale: the workspace query passes none)
+    const int PDE = DSH ? d->PD + 1 : d->PD;                            // position planes the tiles cover (DSH: from -1)
     const bool narrow = d->PW < 12;                 // 5..7-position rows: only worth it with every channel resident (rows outermost)
     if (!PAD && ((d->PD - 1) * S + KD > d->AD || (d->PH - 1) * S + KH > d->AH || (d->PW - 1) * S + KW > d->AW)) return -1;
     // LDS per block: measured sweep (tools/layer_bench.py over a build-time cap): 56 KB is best or equal for every layer of the net
@@ -1039,10 +1074,10 @@ int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const fl
     for (int td = 1; td <= 4 && td <= d->PD; ++td)
         for (int th = 1; th <= d->PH; ++th) {
             WgradRowsParams p; p.d = *d;
-            p.TPD = td; p.TPH = th; p.LD = (td - 1) * S + KD; p.AR = (th - 1) * S + KH; p.apl = p.AR * d->AW;
+            p.TPD = td; p.TPH = th; p.LD = (td - 1) * S + KDW; p.AR = (th - 1) * S + KH; p.apl = p.AR * d->AW;
             p.a_front = front;
             p.a_slot = (int)((((size_t)p.LD * p.apl + front + 4 + 16 * S + 3) / 4) * 4);     // back slack: rounded-up k-steps of the last row
-            size_t f = (size_t)td * th * d->PW + 24; while (f % 32 != 2) ++f;       // +24: rounded-up k-steps read past the last row
+            size_t f = (size_t)(td + (DSH ? 1 : 0)) * th * d->PW + 24; while (f % 32 != 2) ++f;       // +24: rounded-up k-steps read past the last row
             p.bch = (int)f;
             p.nbuf = 0;
             const int opts[3] = {CA, 2, 1};
@@ -1053,20 +1088,20 @@ int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const fl
             }
             if (!p.nbuf || (narrow && p.nbuf != CA)) continue;
             const int rows = td * th, pos = rows * d->PW;
-            const double util = ((double)d->PH / (vg_cdiv(d->PH, th) * th)) * ((double)d->PD / (vg_cdiv(d->PD, td) * td)) *
+            const double util = ((double)d->PH / (vg_cdiv(d->PH, th) * th)) * ((double)PDE / (vg_cdiv(PDE, td) * td)) *
                                 ((double)rows / (4 * vg_cdiv(rows, 4)));
             const double halo = (double)(td * S) * (th * S) / ((double)p.LD * p.AR);
             double score = util * pos / (pos + 96.0) * (0.6 + 0.4 * halo);
             if (p.nbuf == 1 && CA > 1) score *= 0.6;
             // few-item layers (encoder end, 32 samples): one wave per SIMD runs its whole dependent chain exposed -- prefer
             // tiles small enough that every CU gets a couple of blocks
-            const long items = (long)d->N * vg_cdiv(d->PD, td) * vg_cdiv(d->PH, th);
+            const long items = (long)d->N * vg_cdiv(PDE, td) * vg_cdiv(d->PH, th);
             if (items < 512) score *= ((double)items / 512.0) * ((double)items / 512.0);
             if (score > best_score) { best_score = score; best = p; }
         }
     if (best_score < 0) return -1;
     WgradRowsParams p = best;
-    p.nph = vg_cdiv(d->PH, p.TPH); p.pdblocks = vg_cdiv(d->PD, p.TPD);
+    p.nph = vg_cdiv(d->PH, p.TPH); p.pdblocks = vg_cdiv(PDE, p.TPD);
     p.b_off = p.nbuf * p.a_slot;
     size_t fl = (size_t)p.b_off + (size_t)d->CB * p.bch + 64;
     if (fl < red_fl) fl = red_fl;
@@ -1079,7 +1114,7 @@ int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const fl
     using kern_t = void (*)(const float*, const float*, const float*, const float*, float*, WgradRowsParams);
     kern_t kern;
     const bool res = CA > 1 && p.nbuf == CA;
-#define VG_PICK(PA_, RES_) (ug == 4 ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, PA_, 4, RES_> : ug == 3 ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, PA_, 3, RES_> : wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, PA_, 2, RES_>)
+#define VG_PICK(PA_, RES_) (ug == 4 ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, PA_, 4, RES_, false, DSH> : ug == 3 ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, PA_, 3, RES_, false, DSH> : wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, PA_, 2, RES_, false, DSH>)
     if (CA > 1 && res) kern = d->pro_on_a ? VG_PICK(true, true) : VG_PICK(false, true);
     else kern = d->pro_on_a ? VG_PICK(true, false) : VG_PICK(false, false);
 #undef VG_PICK
@@ -1237,6 +1272,11 @@ int dispatch(const vg_wgrad_desc* d, const float* a, const float* b, const float
         if (k333 && d->CA == 8 && d->stride == 2) PLANE(8, 2, 3, 3, 3, 2);
         if (k333 && d->CA == 16 && d->stride == 1) PLANE(16, 2, 3, 3, 3, 1);
         if (k333 && d->CA == 16 && d->stride == 2) PLANE(16, 2, 3, 3, 3, 2);
+        // 8 position channels, stride 2: the plane-shift packing (DSH) fills the 8 idle matrix rows -- 2 instead of 3 / 4 tap tiles
+        if (d->KD == 5 && d->KH == 3 && d->KW == 3 && d->CA == 8 && d->stride == 2 && d->CB == 8)
+            { int r_ = launch_rows<8, 2, 5, 3, 3, 2, false, true>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; }
+        if (d->KD == 4 && d->KH == 4 && d->KW == 4 && d->CA == 8 && d->stride == 2 && d->CB == 8)
+            { int r_ = launch_rows<8, 2, 4, 4, 4, 2, false, true>(d, a, b, in_scale, in_shift, ws, dw, s, ws_only, accumulate); if (r_ >= 0) return r_; }
         if (d->KD == 5 && d->KH == 3 && d->KW == 3 && d->CA == 8 && d->stride == 2) PLANE(8, 3, 5, 3, 3, 2);
         if (d->KD == 4 && d->KH == 4 && d->KW == 4 && d->CA == 8 && d->stride == 2) PLANE(8, 4, 4, 4, 4, 2);
     }
