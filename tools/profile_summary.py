@@ -64,11 +64,12 @@ for (k, grid), v in traffic.items():
 if out:
     json.dump(out, open(os.path.join(out_dir, '%s_hbm_traffic.json' % tag), 'w'), indent=1, sort_keys=True)
     # keyed the way bench.py names its kernels (entry point : layer / direction): the decoder launch (largest traffic) of each instance
-    TABLE = {'vg_tconv3d_s2_stats:convt4/fwd': r'tconv3d_s2_k<8, 5, 3, 3', 'vg_conv_mm:convt4/fwd': r'conv_mm_k<4, ', 'vg_conv_mm:convt3/fwd': r'conv_mm_k<1, 6, 9',
-             'vg_conv_mm:convt3/bwd': r'conv_mm_k<1, 8, 7', 'vg_corr3d:convt4/bwd': r'corr3d_plane_k<8, 5, 3, 3, 2',
-             'vg_corr3d:convt5/fwd': r'corr3d_plane_k<1, 3, 3, 3, 1, 4, 2, 4', 'vg_corr3d:convt3/fwd': r'corr3d_plane_k<8, 3, 3, 3, 1, 1, 1, 4',
-             'vg_wgrad3d_grouped:convt5/bwd': r'wgrad_rows_k<1, 2, 3, 3, 3, 1', 'vg_wgrad3d:convt4/bwd': r'wgrad_rows_k<8, 3, 5, 3, 3, 2',
-             'vg_wgrad3d:convt3/bwd': r'wgrad_rows_k<8, 2, 3, 3, 3, 1', 'vg_bn_bwd_apply_tconv1:convt5/bwd': r'bn_tconv1_k<1, 8>'}
+    TABLE = {'vg_tconv3d_s2_stats:convt2/fwd': r'tconv3d_s2_k<8, 3, 3, 3', 'vg_conv_mm:convt4/fwd': r'conv_mm_k<8, 4, 4, 3, 2, 2, 1',
+             'vg_conv_mm:convt3/fwd': r'conv_mm_k<8, 1, 3, 9', 'vg_conv_mm:convt3/bwd': r'conv_mm_k<8, 1, 3, 7, 0, 0, 0, true',
+             'vg_corr3d:convt4/bwd': r'corr3d_plane_k<8, 5, 3, 3, 2', 'vg_corr3d:convt5/fwd': r'corr3d_plane_k<1, 3, 3, 3, 1, 4, 2, 4',
+             'vg_wgrad3d_grouped:convt5/bwd': r'wgrad_rows_k<1, 2, 3, 3, 3, 1', 'vg_wgrad3d:convt4/bwd': r'wgrad_rows_k<8, 2, 5, 3, 3, 2',
+             'vg_wgrad3d:convt3/bwd': r'wgrad_rows_k<8, 2, 3, 3, 3, 1', 'vg_wgrad3d:convt2/bwd': r'wgrad_rows_k<16, 2, 3, 3, 3, 2, true',
+             'vg_bn_bwd_apply_tconv1:convt5/bwd': r'bn_tconv1_k<1, 8>'}
     by_layer = {}
     for key, sub in TABLE.items():
         cands = [v for k, v in out.items() if sub in k]
