@@ -211,6 +211,15 @@ int vg_gam_elbo_bwd(const float* logits, const float* gain, const float* x, cons
  *   replaces autograd's sum + add launches after torch.nn.BatchNorm3d's backward, vae_reg_GP.py:195-201,216-222). */
 int vg_bn_param_grad(const double* sums, int32_t G, int32_t C, float* dgamma, float* dbeta, int32_t accumulate, void* stream);
 
+/* Batch norm ON THE DATA (bn1, vae_reg_GP.py:187-189, 236-238) folded into conv1's backward: with dw_hat = the weight gradient taken
+ * against the normalised input xhat = x*rstd + nshift (vg_data_bn_nshift: nshift = -mean*rstd) and db = the bias gradient,
+ *   dw[co][ci][t] (+)= gamma[ci]*dw_hat[co][ci][t] + beta[ci]*db[co],   dbias[co] (+)= db[co],
+ *   dgamma[ci] (+)= sum_{co,t} w*dw_hat,   dbeta[ci] (+)= sum_co (sum_t w[co][ci][t]) * db[co]       (accumulate != 0: add into). */
+int vg_data_bn_nshift(const float* mean, const float* rstd, int32_t n, float* nshift, void* stream);
+int vg_data_bn_grads(const float* dw_hat, const float* db, const float* w, const float* gamma, const float* beta,
+                     int32_t CO, int32_t CI, int32_t taps, float* dw, float* dbias, float* dgamma, float* dbeta,
+                     int32_t accumulate, void* stream);
+
 /* Latent sample + KL of the low-rank Gaussian posterior in one launch (vae_reg_GP.py:321-329, 339-342, 400):
  *   d = exp(a) + 1e-6*[any(exp(a) < 1e-6)],  z = mu + w*eps_w + sqrt(d)*eps_d,
  *   kl[b] = 0.5*(-log(1 + sum w^2/d) - sum log d + sum d + sum w^2 + sum mu^2 - L),
@@ -229,6 +238,41 @@ int vg_loss_fwd(const float* kl, const float* slp, const float* dist, const floa
                 double c_kl, double c_slp, double c_gp, double c_dist, float* loss, void* stream);
 int vg_loss_bwd(const float* g_loss, int32_t B, int32_t CB, double c_kl, double c_slp, double c_gp, double c_dist,
                 float* g_kl, float* g_slp, float* g_dist, float* g_gp, void* stream);
+
+/* Fully connected layers (vae_reg_GP.py:197-210 fc1..fc8, :243-259 their use; replaces torch.nn.Linear / F.relu and what autograd
+ * derives from them): one strided product on the matrix cores,
+ *   C[z][m][n] (+)= epilogue( sum_k A[z](m,k) * B[z](k,n) ),   m < M, n < N, k < K, z < batch,
+ * A(m,k) at A + z*a_sb + m*a_sm + k*a_sk, B(k,n) at B + z*b_sb + k*b_sk + n*b_sn (element strides; one stride of each operand must
+ * be 1), C rows contiguous: C + z*c_sb + m*c_sm + n.  flags:
+ *   VG_FC_A_RELU  A <- max(A, 0)                       VG_FC_A_MASK  A <- A * [amask > 0]   (amask laid out as A)
+ *   VG_FC_B_RELU  B <- max(B, 0)                       VG_FC_B_ONES  B gets a column n = N of ones: sum_k A(m,k) goes to cx[z*cx_sb + m]
+ *   VG_FC_C_BIAS  + bias[z*bias_sb + n]                VG_FC_C_RELU  max(., 0)
+ *   VG_FC_C_MASK  * [cmask > 0]  (cmask laid out as C) VG_FC_C_ACCUM add into C / cx instead of overwriting
+ * ksplit > 1 (batch must be 1): the reduction is cut into ksplit pieces of ceil(K/ksplit) rounded up to 64 indices (none may be
+ * empty); partial products go to ws (vg_fc_ws_bytes) and a second launch sums them in a fixed order and applies the epilogue.
+ * Forward of a layer: A = x, B(k,n) = W[n][k], BIAS (+RELU).  Data gradient: A = dy (A_MASK with the layer's output if it has a ReLU),
+ * B(k,n) = W[k][n].  Weight + bias gradient: A(m,k) = dy[k][m], B(k,n) = x[k][n], B_ONES, C = dW, cx = db, C_ACCUM. */
+enum { VG_FC_A_RELU = 1, VG_FC_A_MASK = 2, VG_FC_B_RELU = 4, VG_FC_B_ONES = 8, VG_FC_C_BIAS = 16, VG_FC_C_RELU = 32, VG_FC_C_MASK = 64,
+       VG_FC_C_ACCUM = 128 };
+typedef struct vg_fc_desc {
+    int32_t M, N, K, batch;
+    int64_t a_sm, a_sk, a_sb;
+    int64_t b_sk, b_sn, b_sb;
+    int64_t c_sm, c_sb;
+    int64_t bias_sb, cx_sb;
+    int32_t ksplit, flags;
+} vg_fc_desc;
+int64_t vg_fc_ws_bytes(const vg_fc_desc* d);
+int vg_fc_gemm(const vg_fc_desc* d, const float* A, const float* amask, const float* B, const float* bias, const float* cmask,
+               float* C, float* cx, float* ws, void* stream);
+/* Up to 4 independent products in ONE launch (a layer's data gradient and its weight + bias gradient: these products are latency-bound,
+ * a launch costs as much as the arithmetic); unused pointers NULL. */
+typedef struct vg_fc_job {
+    vg_fc_desc d;
+    const float *A, *amask, *B, *bias, *cmask;
+    float *C, *cx, *ws;
+} vg_fc_job;
+int vg_fc_gemm_jobs(const vg_fc_job* jobs, int32_t njobs, void* stream);
 
 /* Re-pack every conv / transposed-conv weight of the model into the [ci][tap][co] images vg_corr3d / vg_tconv3d_s2 read,
  * in one launch from the flat fp32 parameter buffer.  segs: device array [nseg][8] of int64

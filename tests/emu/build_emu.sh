@@ -8,6 +8,6 @@ SAN=""
 if [ "$1" = "asan" ]; then SAN="-fsanitize=address -fno-omit-frame-pointer"; fi
 OUT="$HERE/libvaegam_emu.so"
 g++ -std=c++20 -O1 -g -fPIC -shared -DVG_EMU $SAN -I"$HERE" -I"$SRC" \
-    -x c++ "$SRC/vg_api.hip" "$SRC/vg_conv.hip" "$SRC/vg_wgrad.hip" "$SRC/vg_bn.hip" "$SRC/vg_gam.hip" "$SRC/vg_chol.hip" "$SRC/vg_latent.hip" "$SRC/vg_gp.hip" "$SRC/vg_conv_mm.hip" \
+    -x c++ "$SRC/vg_api.hip" "$SRC/vg_conv.hip" "$SRC/vg_wgrad.hip" "$SRC/vg_bn.hip" "$SRC/vg_gam.hip" "$SRC/vg_chol.hip" "$SRC/vg_latent.hip" "$SRC/vg_gp.hip" "$SRC/vg_conv_mm.hip" "$SRC/vg_fc.hip" \
     -x c++ "$HERE/hip_emu.cpp" -lpthread -o "$OUT"
 echo "built $OUT"

@@ -192,21 +192,74 @@ def run_linear_case(dev, B=24, fin=40, fout=17, seed=0):
     with torch.no_grad():
         lay.weight.copy_(ref.weight); lay.bias.copy_(ref.bias)
     x = torch.randn(B, fin, generator=g); gy = torch.randn(B, fout, generator=g)
-    for relu in (True, False):
+    for relu, relu_in in ((True, False), (False, False), (True, True)):
         xr = x.clone().requires_grad_(True)
-        yr = ref(xr); yr = torch.relu(yr) if relu else yr
+        yr = ref(torch.relu(xr) if relu_in else xr); yr = torch.relu(yr) if relu else yr
         ref.zero_grad(); (yr * gy).sum().backward()
         for prefilled in (False, True):
             xd = x.to(dev).clone().requires_grad_(True)
             lay.weight.grad = torch.ones_like(lay.weight) if prefilled else None
             lay.bias.grad = torch.ones_like(lay.bias) if prefilled else None
-            y = ops.linear_act(lay, xd, relu)
+            y = ops.linear_act(lay, xd, relu, relu_in=relu_in)
             (y * gy.to(dev)).sum().backward()
             off = 1.0 if prefilled else 0.0
             np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-5, atol=1e-5)
             np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-5)
             np.testing.assert_allclose(lay.weight.grad.cpu().numpy() - off, ref.weight.grad.numpy(), rtol=1e-4, atol=1e-5)
             np.testing.assert_allclose(lay.bias.grad.cpu().numpy() - off, ref.bias.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def run_fc_gemm_case(dev, M, N, K, a_kc, b_kc, flags=(), batch=1, ksplit=None, seed=0):
+    """vg_fc_gemm (the strided product behind every fully connected layer, vae_reg_GP.py:197-210) against a float64 einsum with the
+    same operand options: each operand k-contiguous or m/n-contiguous, ReLU / mask on load, the ones column (bias gradient), bias, ReLU,
+    output mask, accumulation, split-K, batch."""
+    from vae_gam_amd import _lib
+    g = torch.Generator().manual_seed(seed + 7 * M + N + K)
+    fl = 0
+    for f in flags:
+        fl |= getattr(_lib, 'FC_' + f)
+    A = torch.randn(batch, M, K, generator=g); Bm = torch.randn(batch, K, N, generator=g)
+    amask = torch.randn(batch, M, K, generator=g); cmask = torch.randn(batch, M, N, generator=g)
+    bias = torch.randn(batch, N, generator=g); C0 = torch.randn(batch, M, N, generator=g); cx0 = torch.randn(batch, M, generator=g)
+    Ae = A.double()
+    if 'A_RELU' in flags: Ae = Ae.clamp_min(0)
+    if 'A_MASK' in flags: Ae = Ae * (amask > 0)
+    Be = Bm.double().clamp_min(0) if 'B_RELU' in flags else Bm.double()
+    want = torch.einsum('zmk,zkn->zmn', Ae, Be)
+    wx = Ae.sum(2)
+    if 'C_BIAS' in flags: want = want + bias.double()[:, None, :]
+    if 'C_RELU' in flags: want = want.clamp_min(0)
+    if 'C_MASK' in flags: want = want * (cmask > 0)
+    if 'C_ACCUM' in flags: want = want + C0.double(); wx = wx + cx0.double()
+    # device layouts: A as [z][m][k] (k contiguous) or [z][k][m]; B as [z][n][k] (k contiguous) or [z][k][n]
+    Ad = (A if a_kc else A.transpose(1, 2)).contiguous().to(dev); Md = (amask if a_kc else amask.transpose(1, 2)).contiguous().to(dev)
+    Bd = (Bm.transpose(1, 2) if b_kc else Bm).contiguous().to(dev)
+    Cd = C0.clone().to(dev); cxd = cx0.clone().to(dev)
+    a_str = (K, 1, M * K) if a_kc else (1, M, M * K)
+    b_str = (1, K, N * K) if b_kc else (N, 1, N * K)
+    ops.fc_gemm(Ad, Bd, Cd, M, N, K, a_str, b_str, (N, M * N), fl, batch=batch, bias=bias.to(dev), bias_sb=N, amask=Md, cmask=cmask.to(dev),
+                cx=cxd, cx_sb=M, ksplit=ksplit)
+    scale = max(1.0, float(want.abs().max()))
+    np.testing.assert_allclose(Cd.cpu().double().numpy(), want.numpy(), rtol=0, atol=2e-6 * scale * max(1.0, K ** 0.5))
+    if 'B_ONES' in flags:
+        np.testing.assert_allclose(cxd.cpu().double().numpy(), wx.numpy(), rtol=0, atol=2e-6 * max(1.0, float(wx.abs().max())) * max(1.0, K ** 0.5))
+    else:
+        assert torch.equal(cxd.cpu(), cx0), 'cx touched without VG_FC_B_ONES'
+
+
+FC_GEMM_CASES = [
+    # M, N, K, a_kc, b_kc, flags, batch, ksplit
+    (24, 17, 40, True, True, ('C_BIAS', 'C_RELU'), 1, None),                    # a layer's forward, ragged everywhere
+    (64, 200, 256, True, True, ('A_RELU', 'C_BIAS', 'C_RELU'), 1, 4),           # fc1-like: pre-activation input, split-K
+    (70, 33, 100, True, False, ('A_MASK', 'C_MASK'), 1, None),                  # data gradient through two ReLUs
+    (130, 41, 300, True, False, ('A_MASK',), 1, 3),                             # ... with split-K (fc8's data gradient)
+    (50, 37, 64, False, False, ('A_MASK', 'B_ONES', 'B_RELU', 'C_ACCUM'), 1, None),   # weight + bias gradient, accumulated
+    (150, 101, 80, False, False, ('B_ONES',), 1, 2),                            # ... written, split-K, several tiles
+    (64, 32, 50, True, True, ('C_BIAS',), 3, None),                             # the three heads, batched
+    (32, 50, 64, False, False, ('B_ONES', 'C_ACCUM'), 3, None),                 # their weight gradients
+    (5, 3, 2, False, True, (), 1, None),                                        # smaller than a tile in every direction
+    (870, 900, 20, True, False, ('A_MASK', 'C_BIAS'), 1, None),                 # >= 768 tiles of 32 x 32: the 64 x 64 kernel, ragged edges
+]
 
 
 def run_fused_stats_case(dev, spec, isz, groups=2, per_group=3, seed=0):

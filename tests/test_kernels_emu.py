@@ -66,6 +66,12 @@ def test_linear_act_accumulates_into_grad():
     K.run_linear_case('cpu')
 
 
+@pytest.mark.parametrize('case', K.FC_GEMM_CASES, ids=lambda c: '%dx%dx%d%s%s' % (c[0], c[1], c[2], '-split' if c[7] else '', '-batch' if c[6] > 1 else ''))
+def test_fc_gemm_matches_float64_product(case):
+    M, N, Kd, a_kc, b_kc, flags, batch, ksplit = case
+    K.run_fc_gemm_case('cpu', M, N, Kd, a_kc, b_kc, flags, batch, ksplit)
+
+
 def test_gam_elbo_no_covariates():
     K.run_gam_case('cpu', C=0, B=2, V=700, seed=2)
 

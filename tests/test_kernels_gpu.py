@@ -80,6 +80,21 @@ def test_linear_act_accumulates_into_grad():
     K.run_linear_case('cuda')
 
 
+@pytest.mark.parametrize('case', K.FC_GEMM_CASES, ids=lambda c: '%dx%dx%d%s%s' % (c[0], c[1], c[2], '-split' if c[7] else '', '-batch' if c[6] > 1 else ''))
+def test_fc_gemm_matches_float64_product(case):
+    M, N, Kd, a_kc, b_kc, flags, batch, ksplit = case
+    K.run_fc_gemm_case('cuda', M, N, Kd, a_kc, b_kc, flags, batch, ksplit)
+
+
+def test_fc_gemm_at_network_sizes():
+    """the products of the 41x49x35 network at batch 64 / 8 covariates: fc1 forward (split-K), fc8 forward, its data gradient (split-K)
+    and its weight gradient"""
+    K.run_fc_gemm_case('cuda', 64, 200, 3072, True, True, ('A_RELU', 'C_BIAS', 'C_RELU'))
+    K.run_fc_gemm_case('cuda', 576, 3840, 200, True, True, ('C_BIAS',))
+    K.run_fc_gemm_case('cuda', 576, 200, 3840, True, False, ())
+    K.run_fc_gemm_case('cuda', 3840, 200, 576, False, False, ('B_ONES', 'C_ACCUM'))
+
+
 def test_gam_elbo_no_covariates():
     K.run_gam_case('cuda', C=0, B=2, V=700, seed=2)
 

@@ -103,8 +103,13 @@ def test_step_matches_reference_goldens(golden_dir, name):
                 np.testing.assert_allclose(gf, r64, rtol=2e-3, atol=2e-3, err_msg=k)
             continue
         np.testing.assert_allclose(np.sqrt((gf * gf).sum()), ref_norm, rtol=1e-3, atol=1e-6, err_msg=k)   # grads rel 1e-3
+        # single entries: 2e-3 relative + 2e-3 of the gradient's rms entry.  At these tiny batches (4-6 volumes through five batch
+        # norms) the entries of the decoder-stem gradients (fc8, convt1, convt2, bnt1) are conditioning-limited in fp32: changing only the
+        # SUMMATION ORDER inside the fully connected products moves them by up to 1e-3 of the rms entry (tools/diag/fc_noise.py on MI355X:
+        # fc8.weight 9.5e-4, convt2.weight 2.6e-4, convt1.weight 1.8e-4), and the reference's own fp32 values carry the same noise; the
+        # norms above agree to ~2e-5
         np.testing.assert_allclose(gf[g['grad.%s.idx' % k]], g['grad.%s.val' % k], rtol=2e-3,
-                                   atol=1e-6 + 1e-3 * ref_norm / np.sqrt(gf.size), err_msg=k)
+                                   atol=1e-6 + 2e-3 * ref_norm / np.sqrt(gf.size), err_msg=k)
         if k.startswith('gp.'):                                  # every gain parameter also against the float64 value
             r64 = g['grad64.' + k]
             assert np.linalg.norm(gf - r64) <= 1e-3 * np.linalg.norm(r64) + 1e-6, k

@@ -38,6 +38,19 @@ class GainDesc(ctypes.Structure):
     _fields_ = [('C', i32), ('B', i32), ('n', i32), ('hrf_taps', i32), ('jitter_b', f64), ('jitter_ku', f64), ('prior_var', f64)]
 
 
+class FcDesc(ctypes.Structure):
+    _fields_ = [('M', i32), ('N', i32), ('K', i32), ('batch', i32), ('a_sm', i64), ('a_sk', i64), ('a_sb', i64),
+                ('b_sk', i64), ('b_sn', i64), ('b_sb', i64), ('c_sm', i64), ('c_sb', i64), ('bias_sb', i64), ('cx_sb', i64),
+                ('ksplit', i32), ('flags', i32)]
+
+
+class FcJob(ctypes.Structure):
+    _fields_ = [('d', FcDesc), ('A', vp), ('amask', vp), ('B', vp), ('bias', vp), ('cmask', vp), ('C', vp), ('cx', vp), ('ws', vp)]
+
+
+FC_A_RELU, FC_A_MASK, FC_B_RELU, FC_B_ONES, FC_C_BIAS, FC_C_RELU, FC_C_MASK, FC_C_ACCUM = 1, 2, 4, 8, 16, 32, 64, 128
+
+
 _PROTOS = {
     'vg_version': (ctypes.c_int, []),
     'vg_last_error': (ctypes.c_char_p, []),
@@ -60,6 +73,8 @@ _PROTOS = {
     'vg_bn_bwd_reduce_tconv1': (ctypes.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     'vg_bn_bwd_apply_tconv1': (ctypes.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, f64, vp, vp, i32, vp]),
     'vg_bn_param_grad': (ctypes.c_int, [vp, i32, i32, vp, vp, i32, vp]),
+    'vg_data_bn_nshift': (ctypes.c_int, [vp, vp, i32, vp, vp]),
+    'vg_data_bn_grads': (ctypes.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
     'vg_latent_fwd': (ctypes.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     'vg_latent_bwd': (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     'vg_loss_fwd': (ctypes.c_int, [vp, vp, vp, vp, i32, i32, f64, f64, f64, f64, vp, vp]),
@@ -73,6 +88,9 @@ _PROTOS = {
     'vg_conv_mm_stats_chunks': (i64, [ctypes.POINTER(MmDesc), i32]),
     'vg_conv_mm': (ctypes.c_int, [ctypes.POINTER(MmDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     'vg_gather_f32': (ctypes.c_int, [vp, vp, vp, i64, vp]),
+    'vg_fc_ws_bytes': (i64, [ctypes.POINTER(FcDesc)]),
+    'vg_fc_gemm': (ctypes.c_int, [ctypes.POINTER(FcDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'vg_fc_gemm_jobs': (ctypes.c_int, [ctypes.POINTER(FcJob), i32, vp]),
     'vg_gp_gain_ws_bytes': (i64, [i32, i32, i32]),
     'vg_gp_gain_fwd': (ctypes.c_int, [ctypes.POINTER(GainDesc), vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'vg_gp_gain_bwd': (ctypes.c_int, [ctypes.POINTER(GainDesc), vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]),

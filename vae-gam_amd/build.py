@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['vg_api.hip', 'vg_conv.hip', 'vg_wgrad.hip', 'vg_bn.hip', 'vg_gam.hip', 'vg_chol.hip', 'vg_latent.hip', 'vg_gp.hip', 'vg_conv_mm.hip']
+SOURCES = ['vg_api.hip', 'vg_conv.hip', 'vg_wgrad.hip', 'vg_bn.hip', 'vg_gam.hip', 'vg_chol.hip', 'vg_latent.hip', 'vg_gp.hip', 'vg_conv_mm.hip', 'vg_fc.hip']
 OUT = os.path.join(HERE, 'libvaegam_hip.so')
 
 

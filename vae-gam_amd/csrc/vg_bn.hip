@@ -615,7 +615,67 @@ bn_param_grad_k(const double* __restrict__ sums, int G, int C, int accumulate, f
     dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)a;
     dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)b;
 }
+// The first layer's batch norm sits on the DATA (vae_reg_GP.py:187-189, 236-238: bn1 on the input volume, one channel): its backward
+// needs no gradient w.r.t. the input, and the normalisation is folded into conv1's weight gradient -- dw_hat is taken against
+// xhat = (x - mean) * rstd, then  dw = gamma * dw_hat + beta * db,  dgamma = <w, dw_hat>,  dbeta = <sum_taps w, db>.  As torch
+// expressions + autograd's accumulation that tail was 14 launches (~60 us) at the very end of the step with nothing beside it.
+__global__ void __launch_bounds__(256)
+data_bn_grads_k(const float* __restrict__ dw_hat, const float* __restrict__ db, const float* __restrict__ w,
+                const float* __restrict__ gamma, const float* __restrict__ beta, int CO, int CI, int T, int acc,
+                float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[2][256];
+    const int tid = threadIdx.x, n = CO * CI * T;
+    for (int i = tid; i < n; i += 256) {
+        const int co = i / (CI * T), ci = (i / T) % CI;
+        const float v = gamma[ci] * dw_hat[i] + beta[ci] * db[co];
+        dw[i] = acc ? dw[i] + v : v;
+    }
+    for (int co = tid; co < CO; co += 256) dbias[co] = acc ? dbias[co] + db[co] : db[co];
+    for (int ci = 0; ci < CI; ++ci) {
+        float sg = 0.f, sb = 0.f;
+        for (int i = tid; i < CO * T; i += 256) {
+            const int co = i / T, t = i - co * T;
+            const float wv = w[((size_t)co * CI + ci) * T + t];
+            sg += wv * dw_hat[((size_t)co * CI + ci) * T + t];
+            sb += wv * db[co];
+        }
+        red[0][tid] = sg; red[1][tid] = sb;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            dgamma[ci] = acc ? dgamma[ci] + red[0][0] : red[0][0];
+            dbeta[ci] = acc ? dbeta[ci] + red[1][0] : red[1][0];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void data_bn_nshift_k(const float* __restrict__ mean, const float* __restrict__ rstd, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = -(mean[i] * rstd[i]);
+}
+
 }  // namespace
+
+extern "C" int vg_data_bn_nshift(const float* mean, const float* rstd, int32_t n, float* nshift, void* stream) {
+    if (!mean || !rstd || !nshift || n <= 0) { vg_set_error("vg_data_bn_nshift: bad argument"); return VG_ERR_ARG; }
+    vg_launch(data_bn_nshift_k, dim3(vg_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, mean, rstd, (int)n, nshift);
+    return vg_check_launch("data_bn_nshift");
+}
+
+extern "C" int vg_data_bn_grads(const float* dw_hat, const float* db, const float* w, const float* gamma, const float* beta,
+                                int32_t CO, int32_t CI, int32_t taps, float* dw, float* dbias, float* dgamma, float* dbeta,
+                                int32_t accumulate, void* stream) {
+    if (!dw_hat || !db || !w || !gamma || !beta || !dw || !dbias || !dgamma || !dbeta || CO <= 0 || CI <= 0 || taps <= 0) {
+        vg_set_error("vg_data_bn_grads: bad argument"); return VG_ERR_ARG;
+    }
+    vg_launch(data_bn_grads_k, dim3(1), dim3(256), 0, (hipStream_t)stream, dw_hat, db, w, gamma, beta, (int)CO, (int)CI, (int)taps,
+              (int)accumulate, dw, dbias, dgamma, dbeta);
+    return vg_check_launch("data_bn_grads");
+}
 
 extern "C" int vg_bn_param_grad(const double* sums, int32_t G, int32_t C, float* dgamma, float* dbeta, int32_t accumulate,
                                 void* stream) {

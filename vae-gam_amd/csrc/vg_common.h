@@ -71,10 +71,22 @@ static inline void vg_dma_wait() {}
 // wave barrier; call it from wave-uniform code only
 static inline void vg_dma_wait_wave() { emu_wait(g_emu_block->waves[emu_tid / 64].bar); }
 #else
+#ifdef VG_DMA_ASM
+// The same instruction issued from inline assembly: the compiler does not see an LDS write in flight, so it does not put a
+// `s_waitcnt vmcnt(0)` in front of the next LDS read of the wave (with the builtin it does, whatever the addresses: a copy issued ahead
+// of a compute phase is then waited for at that phase's first read).  Every consumer waits explicitly (vg_dma_wait / vg_wait_vm + barrier).
+__device__ __forceinline__ unsigned vg_lds_addr(const float* p) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)p);      // (the low half of a generic LDS address is the LDS byte offset)
+}
+__device__ __forceinline__ void vg_dma4(const float* gsrc, float* lds_row_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" :: "v"(gsrc), "s"(vg_lds_addr(lds_row_base)) : "memory", "m0");
+}
+#else
 __device__ __forceinline__ void vg_dma4(const float* gsrc, float* lds_row_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_row_base, 4, 0, 0);
 }
+#endif
 __device__ __forceinline__ void vg_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // same instruction; the name says that the caller then reads LDS bytes OTHER lanes of its wave copied (a wave waits as a whole)
 __device__ __forceinline__ void vg_dma_wait_wave() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -99,10 +111,16 @@ static inline void vg_dma_span16(const float* src_lane, float* dst, int n, int l
     for (int o = 0; o + 4 * lane < n; o += 256) for (int e = 0; e < 4; ++e) dst[o + 4 * lane + e] = src_lane[o + e];
 }
 #else
+#ifdef VG_DMA_ASM
+__device__ __forceinline__ void vg_dma16(const float* gsrc, float* lds_row_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(vg_lds_addr(lds_row_base)) : "memory", "m0");
+}
+#else
 __device__ __forceinline__ void vg_dma16(const float* gsrc, float* lds_row_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_row_base, 16, 0, 0);
 }
+#endif
 __device__ __forceinline__ void vg_dma_span16(const float* src_lane, float* dst, int n, int lane) {
     for (; n >= 256; n -= 256, src_lane += 256, dst += 256) vg_dma16(src_lane, dst);
     if (4 * lane < n) vg_dma16(src_lane, dst);

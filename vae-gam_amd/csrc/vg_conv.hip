@@ -308,6 +308,8 @@ corr3d_plane_k(const float* __restrict__ x, const float* __restrict__ wpk, const
             roff[dz][hy] = lp * lplane + (clampi(ih, r_lo, max(r_hi - 1, r_lo)) - r_lo) * d.IW + iw_t;
             // NOPRO (no ReLU / affine on the input: the data-gradient launches): a row outside the tensor reads the zeroed tail of the
             // channel slot instead, so an element costs ONE v_and (column mask) instead of max + fma + and
+            // (applying the prologue in place in LDS after the copy and running the one-channel layer through this path was measured:
+            // 216 fewer vector instructions per channel of ~850, but one more barrier-separated phase per channel: 555 -> 710 us)
             if (NOPRO && !rok[dz][hy]) roff[dz][hy] = p.ch_floats - 32;
         }
     if (NOPRO) {
@@ -336,6 +338,9 @@ corr3d_plane_k(const float* __restrict__ x, const float* __restrict__ wpk, const
     const size_t vol = (size_t)plane * d.ID;
     const float* __restrict__ xsrc = x + (size_t)n * d.CI * vol + (size_t)pl_lo * plane + (size_t)r_lo * d.IW;
     auto stage = [&](int c0, float* buf) {
+#ifdef VG_ABLATE_DMA                                          // diagnostic builds (tools/diag/build_variant.sh): the compute phases alone
+        return;
+#endif
         const int cc = min(p.CCH, d.CI - c0);
         const int nw = (int)(blockDim.x / VG_WAVE);
         for (int c = 0; c < cc; ++c) {
@@ -364,7 +369,11 @@ corr3d_plane_k(const float* __restrict__ x, const float* __restrict__ wpk, const
             vg_dma_wait();
             __syncthreads();
         }
+#ifdef VG_ABLATE_FMA                                          // diagnostic builds: the copy phases alone
+        if (active && d.CI < 0) {
+#else
         if (active) {
+#endif
             for (int c = 0; c < cc; ++c) {
                 const int ci = c0 + c;
                 const float* __restrict__ wc = wpk + (size_t)ci * KVOL * CO + co0;

@@ -582,11 +582,22 @@ class BnConvAct(torch.autograd.Function):
                 assert G == 1
                 # weight gradient against the NORMALISED input xhat = (x-mean)*rstd, then
                 #   dw = gamma*dw_hat + beta*db ;  dgamma = <w, dw_hat> ; dbeta = <sum_k w, db>
-                dw_hat = conv_weight_grad(p_in, dy, spec, False, rstd, -mean * rstd, per_group)
-                g5 = gamma.view(1, -1, 1, 1, 1); b5 = beta.view(1, -1, 1, 1, 1)
-                dw = g5 * dw_hat + b5 * db.view(-1, 1, 1, 1, 1)
-                dgamma = (weight * dw_hat).sum((0, 2, 3, 4))
-                dbeta = (weight.sum((2, 3, 4)) * db.view(-1, 1)).sum(0)
+                # (two small launches instead of 14 torch ones at the very end of the step: vg_data_bn_nshift, vg_data_bn_grads)
+                nshift = torch.empty_like(mean)
+                _call(mean, 'vg_data_bn_nshift', _p(_chk(mean)), _p(_chk(rstd)), mean.numel(), _p(nshift))
+                dw_hat = conv_weight_grad(p_in, dy, spec, False, rstd, nshift, per_group)
+                gg, gbt = _grad_buf(gamma), _grad_buf(beta)
+                acc = wg is not None and bg is not None and gg is not None and gbt is not None
+                taps = spec.k[0] * spec.k[1] * spec.k[2]
+                dw = wg if acc else torch.empty_like(weight)
+                dbo = bg if acc else torch.empty_like(db)
+                dgamma = gg if acc else torch.empty_like(gamma)
+                dbeta = gbt if acc else torch.empty_like(beta)
+                _call(dy, 'vg_data_bn_grads', _p(_chk(dw_hat)), _p(_chk(db)), _p(_chk(weight)), _p(_chk(gamma)), _p(_chk(beta)),
+                      spec.co, spec.ci, taps, _p(dw), _p(dbo), _p(dgamma), _p(dbeta), int(acc))
+                if acc:
+                    return None, None, None, None, None, None, None, None, None, None, None, None
+                db = dbo
             else:
                 dw = conv_weight_grad(p_in, dy, spec, relu_in, None, None, per_group, out=wg)
             return None, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
@@ -802,23 +813,88 @@ class ElboLoss(torch.autograd.Function):
         return g_kl, g_slp, g_dist, g_gp, None
 
 
-_FUSED_RELU_GEMM = hasattr(torch, '_addmm_activation') and bool(int(_os.environ.get('VG_FUSED_RELU_GEMM', '1')))
+def _fc_split(M, N, K):
+    """Split-K factor of a fully connected product.  The kernel keeps four 64-index steps in flight, so a reduction of a few hundred
+    indices is one or two memory round trips and is left whole; a LONG reduction onto few output tiles (fc1: 3072 -> 64 x 200; fc8's data
+    gradient: 3840 -> 576 x 200) is cut into pieces of >= 256 indices until ~1024 blocks exist.  The pieces are sized as the kernel
+    sizes them (ceil(K / ksplit) rounded up to 64) and none may be empty."""
+    tiles = ((M + 31) // 32) * ((N + 31) // 32)
+    if K <= 1024:
+        return 1
+    ks = max(1, min(K // 256, 1024 // tiles))
+    if ks <= 1:
+        return 1
+    kchunk = (((K + ks - 1) // ks) + 63) // 64 * 64
+    return (K + kchunk - 1) // kchunk
+
+
+def fc_job(A, B, C, M, N, K, a_strides, b_strides, c_strides, flags=0, batch=1, bias=None, bias_sb=0, amask=None, cmask=None,
+           cx=None, cx_sb=0, ksplit=None):
+    """One product for vg_fc_gemm_jobs: C[z][m][n] (+)= epilogue(sum_k A[z](m,k) B[z](k,n)); a_strides = (sm, sk, sb),
+    b_strides = (sk, sn, sb), c_strides = (sm, sb), all in elements (include/vaegam.h).  Returns (job struct, tensors to keep alive)."""
+    lib = _lib.get_lib()
+    if ksplit is None:
+        ksplit = _fc_split(M, N + (1 if flags & _lib.FC_B_ONES else 0), K) if batch == 1 else 1
+    d = _lib.FcDesc(M, N, K, batch, a_strides[0], a_strides[1], a_strides[2], b_strides[0], b_strides[1], b_strides[2],
+                    c_strides[0], c_strides[1], bias_sb, cx_sb, ksplit, flags)
+    ws = None
+    if ksplit > 1:
+        ws = torch.empty(lib.size('vg_fc_ws_bytes', ctypes.byref(d)) // 4, dtype=torch.float32, device=C.device)
+    ptr = lambda t: None if t is None else t.data_ptr()
+    return _lib.FcJob(d, ptr(A), ptr(amask), ptr(B), ptr(bias), ptr(cmask), ptr(C), ptr(cx), ptr(ws)), (A, B, C, bias, amask, cmask, cx, ws)
+
+
+def fc_launch(ref, jobs):
+    """vg_fc_gemm_jobs: the products of `jobs` (fc_job results, <= 4) in one launch on ref's stream."""
+    arr = (_lib.FcJob * len(jobs))(*[j[0] for j in jobs])
+    _call(ref, 'vg_fc_gemm_jobs', arr, len(jobs))
+
+
+def fc_gemm(A, B, C, *args, **kw):
+    """A single product (see fc_job)."""
+    fc_launch(C, [fc_job(A, B, C, *args, **kw)])
+    return C
+
+
+def _fc_forward(x, weight, bias, relu, relu_in):
+    M, K = x.shape; N = weight.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    fl = _lib.FC_C_BIAS | (_lib.FC_C_RELU if relu else 0) | (_lib.FC_A_RELU if relu_in else 0)
+    return fc_gemm(x, weight, y, M, N, K, (x.stride(0), 1, 0), (1, weight.stride(0), 0), (N, 0), fl, bias=bias)
+
+
+def _fc_backward(gy, x, weight, y, relu_in, need_gx, wg, bg):
+    """Gradients of y = [relu](x' W^T + b), x' = relu(x) if relu_in: gy is masked with y > 0 inside both products (y None: no ReLU);
+    -> (gx or None, gw or None, gb or None); wg / bg (the .grad views) are added into when given.  ONE launch: the data gradient and
+    the weight gradient (whose extra column is the bias gradient) are two jobs of vg_fc_gemm_jobs."""
+    M, N = gy.shape; K = x.shape[1]
+    am = _lib.FC_A_MASK if y is not None else 0
+    jobs = []
+    gx = None
+    if need_gx:
+        gx = torch.empty((M, K), dtype=torch.float32, device=gy.device)
+        jobs.append(fc_job(gy, weight, gx, M, K, N, (N, 1, 0), (weight.stride(0), 1, 0), (K, 0), am | (_lib.FC_C_MASK if relu_in else 0),
+                           amask=y, cmask=x if relu_in else None))
+    acc = wg is not None and bg is not None
+    gw = wg if acc else torch.empty((N, K), dtype=torch.float32, device=gy.device)
+    gb = bg if acc else torch.empty((N,), dtype=torch.float32, device=gy.device)
+    jobs.append(fc_job(gy, x, gw, N, K, M, (1, N, 0), (x.stride(0), 1, 0), (K, 0),
+                       am | _lib.FC_B_ONES | (_lib.FC_B_RELU if relu_in else 0) | (_lib.FC_C_ACCUM if acc else 0), amask=y, cx=gb))
+    fc_launch(gy, jobs)
+    return gx, (None if acc else gw), (None if acc else gb)
 
 
 class LinearAct(torch.autograd.Function):
-    """y = [relu](x @ W^T + b) for the fully connected layers (vae_reg_GP.py:203-209, 224-234): the GEMMs stay in
-    hipBLASLt (plain library GEMMs), but the backward adds dW / db straight into the .grad views of the flat gradient
-    buffer (GEMM / GEMV with beta = 1) instead of autograd's separate reduce + accumulate launches."""
+    """y = [relu]([relu](x) @ W^T + b) for the fully connected layers (vae_reg_GP.py:203-209, 224-234, 243-259) on vg_fc_gemm: bias and
+    ReLU in the product's epilogue, the ReLU of a pre-activation input (conv5's output, :243) in its operand load; the backward is two
+    launches -- the data gradient and the weight gradient whose extra column is the bias gradient, both masking the incoming gradient
+    with y > 0 on load and adding dW / db straight into the .grad views of the flat gradient buffer."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu):
-        if relu and _FUSED_RELU_GEMM:
-            y = torch._addmm_activation(bias, x, weight.t())             # bias + ReLU in the GEMM epilogue (one launch)
-        else:
-            y = torch.addmm(bias, x, weight.t())
-            if relu:
-                y = torch.relu_(y)
-        ctx.relu = relu
+    def forward(ctx, x, weight, bias, relu, relu_in=False):
+        x = _chk(x.contiguous()); _chk(weight); _chk(bias)
+        y = _fc_forward(x, weight, bias, relu, relu_in)
+        ctx.relu, ctx.relu_in = relu, relu_in
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.bias_ref = bias
         return y
@@ -827,48 +903,25 @@ class LinearAct(torch.autograd.Function):
     def backward(ctx, gy):
         x, weight, y = ctx.saved_tensors
         bias = ctx.bias_ref
-        if ctx.relu:
-            gy = torch.ops.aten.threshold_backward(gy, y, 0.0)
-        gx = None
-        if ctx.needs_input_grad[0]:
-            if gy.is_cuda and gy.shape[1] >= 16384:
-                # a reduction over tens of thousands of columns into a (rows x 200) result (fc8 at 82x98x70: 208 x 66,560 x 200): rocBLAS
-                # picks a kernel without split-K there -- 3.6 ms against hipBLASLt's 0.25 ms (tools/diag/gemm_probe.py), 10 % of that step
-                prev = torch.backends.cuda.preferred_blas_library()
-                torch.backends.cuda.preferred_blas_library('cublaslt')
-                try:
-                    gx = gy @ weight
-                finally:
-                    torch.backends.cuda.preferred_blas_library(prev)
-            else:
-                gx = gy @ weight
-        wg, bg = _grad_buf(weight), _grad_buf(bias)
-        gw = gb = None
-        if wg is not None and bg is not None:
-            # dW / db are needed only by the optimiser: the two small launches go to the second stream, off the dX chain
-            # that the rest of the backward pass waits for (joined when the backward pass ends)
-            ones = _ones(gy.shape[0], gy.device)
-            with on_side_stream(gy, gy, x, wg, bg, ones, enabled=FC_SIDE_STREAM):
-                wg.addmm_(gy.t(), x)
-                bg.addmv_(gy.t(), ones)
-            return gx, None, None, None
-        gw = gy.t() @ x
-        gb = gy.sum(0)
-        return gx, gw, gb, None
+        gy = _chk(gy.contiguous())
+        gx, gw, gb = _fc_backward(gy, x, weight, y, ctx.relu_in, ctx.needs_input_grad[0], _grad_buf(weight), _grad_buf(bias))
+        return gx, gw, gb, None, None
 
 
 class HeadsAct(torch.autograd.Function):
-    """The three encoder heads (vae_reg_GP.py:205-209, 246-252: fc31/32/33 -> ReLU -> fc41/42/43) as ONE GEMM over the stacked
-    first-stage weights and ONE batched GEMM over the second stage.  W3 [3*H, F], b3 [3*H], W4 [3, L, H], b4 [3, 1, L] are
+    """The three encoder heads (vae_reg_GP.py:205-209, 246-252: fc31/32/33 -> ReLU -> fc41/42/43) as ONE product over the stacked
+    first-stage weights and ONE batched product over the second stage.  W3 [3*H, F], b3 [3*H], W4 [3, L, H], b4 [3, 1, L] are
     views of the flat parameter buffer (the optimiser lays the six weights / six biases out back to back), gW3.. the matching
-    views of the flat gradient buffer, which the backward adds into directly.  9 -> 3 launches forward, 23 -> 8 backward."""
+    views of the flat gradient buffer, which the backward adds into directly.  9 -> 2 launches forward, 23 -> 2 backward."""
 
     @staticmethod
     def forward(ctx, h, W3, b3, W4, b4, gW3, gb3, gW4, gb4):
         B = h.shape[0]
-        y = torch._addmm_activation(b3, h, W3.t()) if _FUSED_RELU_GEMM else torch.relu_(torch.addmm(b3, h, W3.t()))   # (B, 3H)
-        X = y.view(B, 3, -1).transpose(0, 1)                             # (3, B, H), strided view
-        out = torch.baddbmm(b4, X, W4.transpose(1, 2))                   # (3, B, L)
+        h = _chk(h.contiguous())
+        G, L, H = W4.shape
+        y = _fc_forward(h, W3, b3, True, False)                          # (B, 3H)
+        out = torch.empty((G, B, L), dtype=torch.float32, device=h.device)
+        fc_gemm(y, W4, out, B, L, H, (G * H, 1, H), (1, H, L * H), (L, B * L), _lib.FC_C_BIAS, batch=G, bias=b4, bias_sb=L)
         ctx.save_for_backward(h, y, W3, W4)
         ctx.grads = (gW3, gb3, gW4, gb4)
         return out
@@ -878,16 +931,13 @@ class HeadsAct(torch.autograd.Function):
         h, y, W3, W4 = ctx.saved_tensors
         gW3, gb3, gW4, gb4 = ctx.grads
         B = h.shape[0]
-        gout = gout.contiguous()
-        X = y.view(B, 3, -1).transpose(0, 1)
-        gX = torch.bmm(gout, W4)                                         # (3, B, H)
-        gW4.baddbmm_(gout.transpose(1, 2), X)                            # += gout^T X
-        ones = _ones(B, gout.device)
-        gb4.baddbmm_(ones.view(1, 1, B).expand(3, 1, B), gout)           # += column sums
-        gy = torch.ops.aten.threshold_backward(gX.transpose(0, 1).reshape(B, -1), y, 0.0)
-        gh = gy @ W3
-        gW3.addmm_(gy.t(), h)
-        gb3.addmv_(gy.t(), ones)
+        G, L, H = W4.shape
+        gout = _chk(gout.contiguous())
+        gX = torch.empty((B, G * H), dtype=torch.float32, device=h.device)           # gradient w.r.t. y, before its ReLU mask
+        fc_launch(gout, [fc_job(gout, W4, gX, B, H, L, (L, 1, B * L), (H, 1, L * H), (G * H, H), 0, batch=G),
+                         fc_job(gout, y, gW4, L, H, B, (1, L, B * L), (G * H, 1, H), (H, L * H), _lib.FC_B_ONES | _lib.FC_C_ACCUM, batch=G,
+                                cx=gb4, cx_sb=L)])
+        gh, _, _ = _fc_backward(gX, h, W3, y, False, True, gW3, gb3)
         return gh, None, None, None, None, None, None, None, None
 
 
@@ -901,8 +951,8 @@ def _ones(n, device):
     return _ONES[key]
 
 
-def linear_act(layer, x, relu):
-    return LinearAct.apply(x, layer.weight, layer.bias, relu)
+def linear_act(layer, x, relu, relu_in=False):
+    return LinearAct.apply(x, layer.weight, layer.bias, relu, relu_in)
 
 
 def gam_maps(logits, gain, x, eps, glm):

@@ -299,8 +299,7 @@ class VAE(nn.Module):
         """-> mu (B,L), w (B,L), a (B,L) with u = w[..., None], d = exp(a)."""
         p = self._encode_pre(x)
         la = ops.linear_act
-        h = F.relu(p).reshape(p.shape[0], -1)
-        h = la(self.fc1, h, True)
+        h = la(self.fc1, p.reshape(p.shape[0], -1), True, relu_in=True)          # conv5's ReLU (:243) in fc1's operand load
         h = la(self.fc2, h, True)
         if self._heads is not None and self._heads[0].device == h.device:
             out = ops.HeadsAct.apply(h, *self._heads)                    # the three heads: one GEMM + one batched GEMM
@@ -466,12 +465,17 @@ class VAE(nn.Module):
         gains_stream = self._gains_stream(dev)
         if gains_stream is not None:
             main = torch.cuda.current_stream(dev)
-            gains_stream.wait_stream(main)
+            gains_stream.wait_stream(main)                               # forks HERE: the block needs nothing the encoder produces
+        heads = self._encode_heads(x, stacked=True)
+        # ... but it is LAUNCHED here, between the encoder and the decoder.  In a replayed hipGraph a branch starts behind whatever its
+        # parent queue held when the branch's first node was created, and autograd runs the backward nodes in reverse creation order:
+        # created first, the block's forward delayed the encoder by its own length and its backward ran after everything else, alone
+        # at the end of the step (rocprofv3 kernel trace: 0.10 + 0.15 ms of 7.06); created here, both sit beside the decoder's layers
+        if gains_stream is not None:
             with torch.cuda.stream(gains_stream):
                 gains = self._gains(covariates, eps_beta, join_stream=main, hrf_in_kernel=not hrf_across)
         else:
             gains = self._gains(covariates, eps_beta, hrf_in_kernel=not hrf_across)
-        heads = self._encode_heads(x, stacked=True)
         G = C + 1
         # d = exp(a) + 1e-6*[any(d < 1e-6)] (:321-323, no sync), z = rsample (:325), kl_z (:400) and the G decoder
         # inputs [z, onehot] (:326-329, 339-342) in ONE launch (and one for the backward)
