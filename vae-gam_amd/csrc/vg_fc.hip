@@ -106,38 +106,63 @@ __device__ __forceinline__ void fc_body(const FcArgs& p, int b, float* __restric
     float ra[FC_DEPTH][FC_U][4], rm[FC_DEPTH][FC_U][4], rb[FC_DEPTH][FC_U][4];
     // (no divergent choice between load forms either: two exec-masked paths that write the same registers make the compiler wait
     // between them.  The 16-byte form is chosen per operand for the whole launch -- K a multiple of 4 -- and reads a clamped quad.)
+    // Address arithmetic and selects are most of a step's instructions (first version: 475 vector instructions per step beside 16 MFMAs,
+    // and the SIMD that issues them is the one that runs the MFMAs): row pointers are formed once, offsets are 32-bit, and a step whose
+    // tile lies inside both operands and inside K skips every validity select.
     const int klast = ke - 1, qlast = max(ke - 4, 0) & ~3;
+    const int ask = (int)d.a_sk, bsk = (int)d.b_sk;
+    const ptrdiff_t mdelta = Am - A;
+    const float* pa[FC_U]; const float* pb[FC_U];
+#pragma unroll
+    for (int i = 0; i < FC_U; ++i) {
+        pa[i] = A + (size_t)min(m0 + ar[i], d.M - 1) * d.a_sm;
+        pb[i] = B + (size_t)min(n0 + br[i], d.N - 1) * d.b_sn;
+    }
     auto fetch = [&](int k0, float (&xa)[FC_U][4], float (&xm)[FC_U][4], float (&xb)[FC_U][4]) {
 #pragma unroll
         for (int i = 0; i < FC_U; ++i) {
-            const int m = min(m0 + ar[i], d.M - 1), k = k0 + 4 * aq[i];
+            const int k = k0 + 4 * aq[i];
             if (AV) {
-                const size_t o = (size_t)m * d.a_sm + (size_t)min(k, qlast);
-                const float4 t = *reinterpret_cast<const float4*>(A + o);
+                const float* q = pa[i] + min(k, qlast);
+                const float4 t = *reinterpret_cast<const float4*>(q);
                 xa[i][0] = t.x; xa[i][1] = t.y; xa[i][2] = t.z; xa[i][3] = t.w;
-                const float4 q4 = *reinterpret_cast<const float4*>(Am + o); xm[i][0] = q4.x; xm[i][1] = q4.y; xm[i][2] = q4.z; xm[i][3] = q4.w;
+                const float4 q4 = *reinterpret_cast<const float4*>(q + mdelta); xm[i][0] = q4.x; xm[i][1] = q4.y; xm[i][2] = q4.z; xm[i][3] = q4.w;
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const size_t o = (size_t)m * d.a_sm + (size_t)min(k + e, klast) * d.a_sk;
-                    xa[i][e] = A[o];
-                    xm[i][e] = Am[o];
+                    const float* q = pa[i] + min(k + e, klast) * ask;
+                    xa[i][e] = *q;
+                    xm[i][e] = q[mdelta];
                 }
             }
         }
 #pragma unroll
         for (int i = 0; i < FC_U; ++i) {
-            const int n = min(n0 + br[i], d.N - 1), k = k0 + 4 * bq[i];
+            const int k = k0 + 4 * bq[i];
             if (BV) {
-                const float4 t = *reinterpret_cast<const float4*>(B + (size_t)min(k, qlast) + (size_t)n * d.b_sn);
+                const float4 t = *reinterpret_cast<const float4*>(pb[i] + min(k, qlast));
                 xb[i][0] = t.x; xb[i][1] = t.y; xb[i][2] = t.z; xb[i][3] = t.w;
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) xb[i][e] = B[(size_t)min(k + e, klast) * d.b_sk + (size_t)n * d.b_sn];
+                for (int e = 0; e < 4; ++e) xb[i][e] = pb[i][min(k + e, klast) * bsk];
             }
         }
     };
+    const bool inside = m0 + FC_T <= d.M && n0 + FC_T <= d.N;          // (the ones column, n = N, is never in such a tile)
+    const float alo = a_relu ? 0.f : -__builtin_inff(), blo = b_relu ? 0.f : -__builtin_inff();
     auto put = [&](int k0, const float (&xa)[FC_U][4], const float (&xm)[FC_U][4], const float (&xb)[FC_U][4]) {
+        if (inside && k0 + FC_TK <= ke) {
+#pragma unroll
+            for (int i = 0; i < FC_U; ++i) {
+                float4 t, u4;
+                t.x = vg_max((xm[i][0] > mthr) ? xa[i][0] : 0.f, alo); t.y = vg_max((xm[i][1] > mthr) ? xa[i][1] : 0.f, alo);
+                t.z = vg_max((xm[i][2] > mthr) ? xa[i][2] : 0.f, alo); t.w = vg_max((xm[i][3] > mthr) ? xa[i][3] : 0.f, alo);
+                u4.x = vg_max(xb[i][0], blo); u4.y = vg_max(xb[i][1], blo); u4.z = vg_max(xb[i][2], blo); u4.w = vg_max(xb[i][3], blo);
+                *reinterpret_cast<float4*>(&As[ar[i] * FC_PITCH + 4 * aq[i]]) = t;
+                *reinterpret_cast<float4*>(&Bs[br[i] * FC_PITCH + 4 * bq[i]]) = u4;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < FC_U; ++i) {
             float va[4], vb[4];
