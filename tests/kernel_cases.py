@@ -32,6 +32,10 @@ WIDE_LAYERS = [
     ('convt4_wide', ConvSpec('convt', 8, 8, (5, 3, 3), 2), (3, 5, 12)),
     ('convt4hr_wide', ConvSpec('convt', 8, 8, (4, 4, 4), 2), (3, 3, 12)),
     ('convt5_wide', ConvSpec('convt', 8, 1, (3, 3, 3), 1), (4, 7, 13)),
+    # planes so large that ONE channel's planes fill the plane-staged kernel's LDS budget (one channel per chunk, as in the 41x49x35
+    # network's large layers)
+    ('convt5_split', ConvSpec('convt', 3, 1, (3, 3, 3), 1), (4, 36, 36)),
+    ('convt4_split', ConvSpec('convt', 8, 8, (5, 3, 3), 2), (3, 16, 16)),
 ]
 
 

@@ -518,6 +518,13 @@ int launch_corr_plane(const vg_conv_desc* d, const float* x, const float* wpk, c
     if (cch > d->CI) cch = d->CI;
     if (p.nbuf == 2 && cch >= d->CI) { p.nbuf = 1; }      // everything fits one chunk: nothing to overlap
     p.CCH = cch;
+    // (Round 3, measured and NOT kept: split-phase staging for the layers whose chunk is one channel in one buffer -- planes [0, h) of the
+    // next channel copied behind the FMAs on planes [h, LD) of this one and the other way round, copies issued from inline assembly so
+    // that the compiler does not wait for them at the next LDS read.  With the copy / FMA phases ablated in turn convt4's data gradient is
+    // 275 us of copies + 323 us of FMAs in 454 us and convt5 forward 269 + 443 in 535, so perfect overlap would save ~0.2 ms; the split
+    // gave 494 and 553-583 us: half a channel of FMAs (~1 us) is shorter than a copy's latency, and where a block spans two output-plane
+    // groups its waves need different halves, so each phase waits for its slowest wave.  What would work is a second buffer, which does
+    // not fit beside the co-resident blocks.)
     const size_t shmem = (size_t)p.ch_floats * cch * p.nbuf * sizeof(float) + (PLANE_SLACK + 64) * sizeof(float);
     if (d->CO % COT) { vg_set_error("corr3d: CO=%d not a multiple of %d", d->CO, COT); return VG_ERR_UNSUPPORTED; }
     const int threads = vg_cdiv(p.TWG * p.TH * p.TD, VG_WAVE) * VG_WAVE;

@@ -83,6 +83,16 @@ def _make_writer(log_dir, enabled):
     return _NullWriter()
 
 
+class _GpPosteriors:
+    """(names, f_bar (K,B), Sigma (K,B,B)) of the GP covariates, unpacked like that tuple; the two gathers out of the gain block's
+    per-covariate arrays (77 us per step for Sigma) run only when somebody asks -- exports and tests, never the train step."""
+    def __init__(self, names, fb, sg, gidx):
+        self.names, self._fb, self._sg, self._gidx = names, fb, sg, gidx
+
+    def __iter__(self):
+        return iter((self.names, self._fb.index_select(0, self._gidx), self._sg.index_select(0, self._gidx)))
+
+
 class VAE(nn.Module):
     def __init__(self, nf=8, save_dir='', lr=1e-3, num_covariates=8, num_latents=32, device_name="auto",
                  num_inducing_pts=6, gp_kl_scale=10.0, glm_maps='', glm_reg_scale=1.0, csv_files='',
@@ -367,11 +377,17 @@ class VAE(nn.Module):
         B = covariate_vals.shape[0]
         return (covariate_vals.unsqueeze(0) @ self._hrf_matrix(B, covariate_vals.device)).squeeze(0)
 
-    def draw_noise(self, B, device):
+    def draw_noise(self, B, device, out=None):
         """The reference's draws per forward, in its order: (B,1), (B,L), then C x (B,)  (SURVEY 4).
         Data-parallel: B is the GLOBAL batch and the draws come from a generator seeded identically on every
         rank, so all ranks hold the same noise and each uses its slice."""
         gen = None if self.dp is None else self.dp.noise_generator(device)
+        if out is not None:
+            # straight into the replayed graph's input buffers: the same generator calls in the same order produce the same values as
+            # torch.randn of these shapes (one Philox stream), without three device-to-device copies in front of every replay
+            assert out['eps_w'].shape == (B, 1) and out['eps_d'].shape == (B, self.num_latents) and out['eps_beta'].shape == (self.num_covariates, B)
+            out['eps_w'].normal_(generator=gen); out['eps_d'].normal_(generator=gen); out['eps_beta'].normal_(generator=gen)
+            return out
         return {'eps_w': torch.randn(B, 1, device=device, generator=gen),
                 'eps_d': torch.randn(B, self.num_latents, device=device, generator=gen),
                 'eps_beta': torch.randn(self.num_covariates, B, device=device, generator=gen)}
@@ -388,7 +404,7 @@ class VAE(nn.Module):
         self.last_gp_kl = kl_terms                      # per covariate: kl_lin (+ kl_gp), float64 (parity tests, logging)
         post = None
         if K['gidx_list']:
-            post = ([K['names'][i] for i in K['gidx_list']], fb.index_select(0, K['gidx']), sg.index_select(0, K['gidx']))
+            post = _GpPosteriors([K['names'][i] for i in K['gidx_list']], fb, sg, K['gidx'])
         return tv, kl, bm, bc, post
 
     def _gains_stream(self, dev):
@@ -551,9 +567,7 @@ class VAE(nn.Module):
             if g is not False:
                 g['x'].copy_(x, non_blocking=True); g['cov'].copy_(covariates, non_blocking=True)
                 Bg = x.shape[0] * (1 if self.dp is None else self.dp.world_size)
-                fresh = self.draw_noise(Bg, x.device)                   # same draws, same order as the eager path
-                for k in fresh:
-                    g['noise'][k].copy_(fresh[k])
+                self.draw_noise(Bg, x.device, out=g['noise'])           # same draws, same order as the eager path
                 g['graph'].replay()                                     # includes the device-side Adam step-count advance
                 self.optimizer.step_count += 1                          # host mirror of the device count
                 return g['loss']
