@@ -737,6 +737,8 @@ __device__ unsigned long long vg_wg_stamp_out[2048 * 4 * 8];
 #define VG_WS_ADD(i) do {} while (0)
 #endif
 template <int V> struct vg_int { static constexpr int value = V; };
+__host__ __device__ constexpr int vg_ival(int v) { return v; }
+template <int V> __host__ __device__ constexpr int vg_ival(vg_int<V>) { return V; }
 template <int N, int I = 0, typename F>
 __host__ __device__ inline void vg_static_for(F&& f) { if constexpr (I < N) { f(vg_int<I>{}); vg_static_for<N, I + 1>(f); } }
 
@@ -761,7 +763,12 @@ struct WgradRowsParams {
 // position is one plane = S window planes ahead -- accumulates dw[cb][.][kd' - S]: together every kd in [0, KD), from (KD-S)*KH*KW instead
 // of KD*KH*KW window taps (convt4: 27 instead of 45 = 2 instead of 3 matrix instructions per k-step and channel; the 4x4x4 layer of the
 // 82x98x70 geometry: 32 instead of 64 = 2 instead of 4).  The position planes of a tile start at -1 (row h = 1 covers plane 0 there).
-template <int CA, int TC, int KD, int KH, int KW, int S, bool PAD, bool PA, int UG, bool RES, bool GRP = false, bool DSH = false>
+// ONE != 0: a row is ONE >> 1 unrolled blocks of UG k-steps at COMPILE-TIME offsets (rows of 13..16 positions = one block of 4: every
+// large layer of the 41x49x35 network; 33 positions = three blocks of 3: its first and last layer): the LDS reads then carry their
+// offsets as immediates (with the run-time step loop each read had its own address add: 39 vector + 23 scalar instructions per row
+// beside 8 MFMAs, ISA of the convt4 instance); ONE & 1 (PW a multiple of 4): no position mask in the last block either.
+// ONE == 0: the general step loop.  (convt4's weight gradient 627 -> 507 us, convt3's 361 -> 313.)
+template <int CA, int TC, int KD, int KH, int KW, int S, bool PAD, bool PA, int UG, bool RES, bool GRP = false, bool DSH = false, int ONE = 0>
 __global__ void __launch_bounds__(256, (CA * TC >= 32 ? 2 : CA * TC >= 16 ? VG_WG_MINB : 1))         // 32 accumulator tiles: keep two waves per SIMD (<= 256 registers)
 wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ in_scale,
              const float* __restrict__ in_shift, float* __restrict__ ws, WgradRowsParams p) {
@@ -932,8 +939,9 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
         // shuffles all NT*4 of them between register sets on every row.)
         auto row_channel = [&](auto ca_tag, const float* bp, const float* ap, float sc, float sh, const bool* okdh) {
             constexpr int ca = decltype(ca_tag)::value;
-            auto kblock = [&](auto masked_tag, int ks) {
+            auto kblock = [&](auto masked_tag, auto ks_) {         // ks_: int, or vg_int<0> (ONE: compile-time 0)
                 constexpr bool MASKED = decltype(masked_tag)::value != 0;
+                const int ks = vg_ival(ks_);
                 float av[UG], bv[UG][TC];
 #pragma unroll
                 for (int u = 0; u < UG; ++u) {
@@ -958,9 +966,18 @@ wgrad_rows_k(const float* __restrict__ a, const float* __restrict__ b, const flo
                     }
                 }
             };
-            int ks = 0;
-            for (; ks < ksteps - UG; ks += UG) kblock(vg_int<0>{}, ks);
-            kblock(vg_int<1>{}, ks);
+            if constexpr (ONE != 0) {
+                constexpr int NB = ONE >> 1;
+                vg_static_for<NB>([&](auto i_tag) {
+                    constexpr int I = decltype(i_tag)::value;
+                    if constexpr (I + 1 < NB || (ONE & 1)) kblock(vg_int<0>{}, vg_int<I * UG>{});
+                    else kblock(vg_int<1>{}, vg_int<I * UG>{});
+                });
+            } else {
+                int ks = 0;
+                for (; ks < ksteps - UG; ks += UG) kblock(vg_int<0>{}, ks);
+                kblock(vg_int<1>{}, ks);
+            }
         };
         auto row_masks = [&](int dz, int py, bool* okdh) {
 #pragma unroll
@@ -1118,11 +1135,20 @@ int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const fl
     if (CA > 1 && res) kern = d->pro_on_a ? VG_PICK(true, true) : VG_PICK(false, true);
     else kern = d->pro_on_a ? VG_PICK(true, false) : VG_PICK(false, false);
 #undef VG_PICK
+    if (!res && ug == 4 && ksteps == 4) {                   // one block per row (see ONE): convt4 / convt3 / conv2 / conv3 at 41x49x35
+        if (d->PW % 4 == 0) kern = d->pro_on_a ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, true, 4, false, false, DSH, 3> : wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 4, false, false, DSH, 3>;
+        else kern = d->pro_on_a ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, true, 4, false, false, DSH, 2> : wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 4, false, false, DSH, 2>;
+    }
+    if constexpr (CA == 1 && !DSH) {                        // three blocks of 3 per row: the 33-position rows of conv1 / convt5
+        if (!res && ug == 3 && ksteps == 9 && d->PW % 4 != 0)
+            kern = d->pro_on_a ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, true, 3, false, false, false, 6> : wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 3, false, false, false, 6>;
+    }
     if (grouped) {
         if constexpr (CA == 1 && !PAD) {
             if (d->pro_on_a) return -1;
             kern = ug == 4 ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 4, false, true> : ug == 3 ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 3, false, true>
                            : wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 2, false, true>;
+            if (ug == 3 && ksteps == 9 && d->PW % 4 != 0) kern = wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 3, false, true, false, 6>;
         } else return -1;
     }
     int per_cu = vg_blocks_per_cu((const void*)kern, 256, fl * sizeof(float));   // persistent grid == resident blocks
