@@ -36,6 +36,9 @@ WIDE_LAYERS = [
     # network's large layers)
     ('convt5_split', ConvSpec('convt', 3, 1, (3, 3, 3), 1), (4, 36, 36)),
     ('convt4_split', ConvSpec('convt', 8, 8, (5, 3, 3), 2), (3, 16, 16)),
+    # 33 positions per row (the first and the last layer of the 41x49x35 network): the weight-gradient rows as three compile-time blocks
+    ('conv1_w33', ConvSpec('conv', 1, 8, (3, 3, 3), 1), (4, 5, 35)),
+    ('convt5_w33', ConvSpec('convt', 8, 1, (3, 3, 3), 1), (3, 4, 33)),
 ]
 
 
