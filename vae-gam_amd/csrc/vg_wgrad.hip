@@ -1139,6 +1139,12 @@ int launch_rows(const vg_wgrad_desc* d, const float* a, const float* b, const fl
         if (d->PW % 4 == 0) kern = d->pro_on_a ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, true, 4, false, false, DSH, 3> : wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 4, false, false, DSH, 3>;
         else kern = d->pro_on_a ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, true, 4, false, false, DSH, 2> : wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 4, false, false, DSH, 2>;
     }
+    if constexpr (CA > 1 && !DSH) {                         // ... and the narrow rows (4..8 positions, every channel resident): convt1 / convt2 / conv4 / conv5
+        if (res && ug == 2 && ksteps <= 2) {
+            if (d->PW == 8) kern = d->pro_on_a ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, true, 2, true, false, false, 3> : wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 2, true, false, false, 3>;
+            else kern = d->pro_on_a ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, true, 2, true, false, false, 2> : wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 2, true, false, false, 2>;
+        }
+    }
     if constexpr (CA == 1 && !DSH) {                        // three blocks of 3 per row: the 33-position rows of conv1 / convt5
         if (!res && ug == 3 && ksteps == 9 && d->PW % 4 != 0)
             kern = d->pro_on_a ? wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, true, 3, false, false, false, 6> : wgrad_rows_k<CA, TC, KD, KH, KW, S, PAD, false, 3, false, false, false, 6>;
