@@ -606,6 +606,9 @@ tconv3d_s2_k(const float* __restrict__ x, const float* __restrict__ wpk, const f
     const float lo = d.relu_in ? 0.f : -__builtin_inff();
     const size_t vol = (size_t)d.ID * d.IH * d.IW;
     // software pipeline over channels: the next channel's window is in flight behind this channel's FMAs
+    // (the weights are wave-uniform scalar loads used once per lane, requested right in front of their FMAs -- nine
+    // `s_waitcnt lgkmcnt(0)` per channel in the ISA.  Requesting tap group g+1's weights before group g's FMAs was measured:
+    // convt2 forward 245 -> 261 us; the four waves per SIMD already cover that latency.)
     float nxt[MD][MH][MW];
     const float* __restrict__ xbase = x + (size_t)n * d.CI * vol;
 #pragma unroll
