@@ -265,6 +265,9 @@ FC_GEMM_CASES = [
     (64, 32, 50, True, True, ('C_BIAS',), 3, None),                             # the three heads, batched
     (32, 50, 64, False, False, ('B_ONES', 'C_ACCUM'), 3, None),                 # their weight gradients
     (5, 3, 2, False, True, (), 1, None),                                        # smaller than a tile in every direction
+    (64, 40, 96, False, False, ('A_MASK', 'B_ONES', 'C_ACCUM'), 1, None),       # both operands contiguous along m / n, multiples of 4: 16-byte loads across rows
+    (36, 44, 70, False, False, ('A_RELU', 'B_ONES', 'B_RELU'), 1, None),        # ... ragged tile edges and a partial last step
+    (72, 36, 200, True, False, ('A_MASK', 'C_MASK'), 1, 2),                     # data gradient with the weights read across rows, split-K
     (870, 900, 20, True, False, ('A_MASK', 'C_BIAS'), 1, None),                 # >= 768 tiles of 32 x 32: the 64 x 64 kernel, ragged edges
 ]
 

@@ -43,7 +43,7 @@ struct FcArgs {
     const float* A; const float* amask; const float* B; const float* bias; const float* cmask;
     float* C; float* cx; float* ws;
     int kchunk;          // reduction indices per split (a multiple of FC_TK); K when ksplit == 1
-    int a_vec, b_vec;    // 16-byte loads allowed (k-contiguous operand, 16-byte aligned rows)
+    int a_vec, b_vec;    // load form of the operand (see fc_body): 0 dwords, 1 16 bytes along k, 2 16 bytes along m / n
     int gx, gy;          // tiles along m and n
     int big;             // 64 x 64 tiles (2 x 2 MFMA tiles per wave) instead of 32 x 32
 };
@@ -66,11 +66,14 @@ __device__ __forceinline__ void fc_store(const FcArgs& p, int z, int m, int n, f
     p.C[o] = (d.flags & VG_FC_C_ACCUM) ? p.C[o] + v : v;
 }
 
-// AV / BV: the operand is read as 16-byte loads (k-contiguous, aligned, K % 4 == 0).  Compile-time, one body per combination: with the
-// two load forms as run-time alternatives inside one body the register allocator shared registers between them and every unit of the
-// dword form began with s_waitcnt vmcnt(0).
+// AV / BV: how an operand is read.  1: 16-byte loads ALONG K (k-contiguous, aligned, K % 4 == 0) -> one 16-byte LDS write.  2: 16-byte
+// loads ALONG M / N (the operand is contiguous along its row index: every weight-gradient operand, the weights of a data gradient;
+// aligned, row count % 4 == 0): a unit is 4 consecutive rows at one k -> four dword LDS writes; a quarter of the load instructions and
+// address arithmetic of form 0.  0: dword loads (any layout).  Compile-time, one body per combination: with the load forms as run-time
+// alternatives inside one body the register allocator shared registers between them and every unit of the dword form began with
+// s_waitcnt vmcnt(0).
 // W: MFMA tiles per wave and direction (tile edge 32 * W).
-template <int W, bool AV, bool BV>
+template <int W, int AV, int BV>
 __device__ __forceinline__ void fc_body(const FcArgs& p, int b, float* __restrict__ As, float* __restrict__ Bs) {
     constexpr int FC_T = 32 * W;
     constexpr int FC_U = FC_T * (FC_TK / 4) / 256;     // 16-byte units per thread, operand and step
@@ -99,6 +102,9 @@ __device__ __forceinline__ void fc_body(const FcArgs& p, int b, float* __restric
         const int u = tid + i * 256;
         ar[i] = a_kc ? u / (FC_TK / 4) : u % FC_T; aq[i] = a_kc ? u % (FC_TK / 4) : u / FC_T;
         br[i] = b_kc ? u / (FC_TK / 4) : u % FC_T; bq[i] = b_kc ? u % (FC_TK / 4) : u / FC_T;
+        // form 2: ar = first of the unit's 4 rows, aq = its k inside the step (lanes along the row groups: 16 contiguous bytes each)
+        if (AV == 2) { ar[i] = 4 * (u % (FC_T / 4)); aq[i] = u / (FC_T / 4); }
+        if (BV == 2) { br[i] = 4 * (u % (FC_T / 4)); bq[i] = u / (FC_T / 4); }
     }
     // fetch() only LOADS (raw operand values, raw mask values; indices clamped into the operand so that no load needs a predicate whose
     // result is consumed at once); zero fill, mask, ReLU and the ones column are applied in put(), four steps later.  (With the
@@ -122,7 +128,12 @@ __device__ __forceinline__ void fc_body(const FcArgs& p, int b, float* __restric
 #pragma unroll
         for (int i = 0; i < FC_U; ++i) {
             const int k = k0 + 4 * aq[i];
-            if (AV) {
+            if (AV == 2) {
+                const float* q = A + min(m0 + ar[i], d.M - 4) + (size_t)min(k0 + aq[i], klast) * d.a_sk;
+                const float4 t = *reinterpret_cast<const float4*>(q);
+                xa[i][0] = t.x; xa[i][1] = t.y; xa[i][2] = t.z; xa[i][3] = t.w;
+                const float4 q4 = *reinterpret_cast<const float4*>(q + mdelta); xm[i][0] = q4.x; xm[i][1] = q4.y; xm[i][2] = q4.z; xm[i][3] = q4.w;
+            } else if (AV == 1) {
                 const float* q = pa[i] + min(k, qlast);
                 const float4 t = *reinterpret_cast<const float4*>(q);
                 xa[i][0] = t.x; xa[i][1] = t.y; xa[i][2] = t.z; xa[i][3] = t.w;
@@ -139,7 +150,10 @@ __device__ __forceinline__ void fc_body(const FcArgs& p, int b, float* __restric
 #pragma unroll
         for (int i = 0; i < FC_U; ++i) {
             const int k = k0 + 4 * bq[i];
-            if (BV) {
+            if (BV == 2) {
+                const float4 t = *reinterpret_cast<const float4*>(B + min(n0 + br[i], d.N - 4) + (size_t)min(k0 + bq[i], klast) * d.b_sk);
+                xb[i][0] = t.x; xb[i][1] = t.y; xb[i][2] = t.z; xb[i][3] = t.w;
+            } else if (BV == 1) {
                 const float4 t = *reinterpret_cast<const float4*>(pb[i] + min(k, qlast));
                 xb[i][0] = t.x; xb[i][1] = t.y; xb[i][2] = t.z; xb[i][3] = t.w;
             } else {
@@ -158,30 +172,35 @@ __device__ __forceinline__ void fc_body(const FcArgs& p, int b, float* __restric
                 t.x = vg_max((xm[i][0] > mthr) ? xa[i][0] : 0.f, alo); t.y = vg_max((xm[i][1] > mthr) ? xa[i][1] : 0.f, alo);
                 t.z = vg_max((xm[i][2] > mthr) ? xa[i][2] : 0.f, alo); t.w = vg_max((xm[i][3] > mthr) ? xa[i][3] : 0.f, alo);
                 u4.x = vg_max(xb[i][0], blo); u4.y = vg_max(xb[i][1], blo); u4.z = vg_max(xb[i][2], blo); u4.w = vg_max(xb[i][3], blo);
-                *reinterpret_cast<float4*>(&As[ar[i] * FC_PITCH + 4 * aq[i]]) = t;
-                *reinterpret_cast<float4*>(&Bs[br[i] * FC_PITCH + 4 * bq[i]]) = u4;
+                if (AV == 2) { float* q = &As[ar[i] * FC_PITCH + aq[i]]; q[0] = t.x; q[FC_PITCH] = t.y; q[2 * FC_PITCH] = t.z; q[3 * FC_PITCH] = t.w; }
+                else *reinterpret_cast<float4*>(&As[ar[i] * FC_PITCH + 4 * aq[i]]) = t;
+                if (BV == 2) { float* q = &Bs[br[i] * FC_PITCH + bq[i]]; q[0] = u4.x; q[FC_PITCH] = u4.y; q[2 * FC_PITCH] = u4.z; q[3 * FC_PITCH] = u4.w; }
+                else *reinterpret_cast<float4*>(&Bs[br[i] * FC_PITCH + 4 * bq[i]]) = u4;
             }
             return;
         }
 #pragma unroll
         for (int i = 0; i < FC_U; ++i) {
             float va[4], vb[4];
-            const int m = m0 + ar[i], ka = k0 + 4 * aq[i];
-            const int n = n0 + br[i], kq = k0 + 4 * bq[i];
+            // element e of a unit: (row, k) = (r, k + e) in forms 0 / 1, (r + e, k) in form 2
+            const int m = m0 + ar[i], ka = k0 + (AV == 2 ? aq[i] : 4 * aq[i]);
+            const int n = n0 + br[i], kq = k0 + (BV == 2 ? bq[i] : 4 * bq[i]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v = (m < d.M && ka + e < ke) ? xa[i][e] : 0.f;
+                const int me = AV == 2 ? m + e : m, kae = AV == 2 ? ka : ka + e;
+                float v = (me < d.M && kae < ke) ? xa[i][e] : 0.f;
                 if (!(xm[i][e] > mthr)) v = 0.f;
                 va[e] = a_relu ? (v > 0.f ? v : 0.f) : v;
-                float w = (n < d.N && kq + e < ke) ? xb[i][e] : 0.f;
+                const int ne = BV == 2 ? n + e : n, kbe = BV == 2 ? kq : kq + e;
+                float w = (ne < d.N && kbe < ke) ? xb[i][e] : 0.f;
                 if (b_relu) w = w > 0.f ? w : 0.f;
-                if (b_ones && n == d.N) w = (kq + e < ke) ? 1.f : 0.f;
+                if (b_ones && ne == d.N) w = (kbe < ke) ? 1.f : 0.f;
                 vb[e] = w;
             }
-            float4 t; t.x = va[0]; t.y = va[1]; t.z = va[2]; t.w = va[3];
-            *reinterpret_cast<float4*>(&As[ar[i] * FC_PITCH + 4 * aq[i]]) = t;
-            float4 u4; u4.x = vb[0]; u4.y = vb[1]; u4.z = vb[2]; u4.w = vb[3];
-            *reinterpret_cast<float4*>(&Bs[br[i] * FC_PITCH + 4 * bq[i]]) = u4;
+            if (AV == 2) { float* q = &As[ar[i] * FC_PITCH + aq[i]]; q[0] = va[0]; q[FC_PITCH] = va[1]; q[2 * FC_PITCH] = va[2]; q[3 * FC_PITCH] = va[3]; }
+            else { float4 t; t.x = va[0]; t.y = va[1]; t.z = va[2]; t.w = va[3]; *reinterpret_cast<float4*>(&As[ar[i] * FC_PITCH + 4 * aq[i]]) = t; }
+            if (BV == 2) { float* q = &Bs[br[i] * FC_PITCH + bq[i]]; q[0] = vb[0]; q[FC_PITCH] = vb[1]; q[2 * FC_PITCH] = vb[2]; q[3 * FC_PITCH] = vb[3]; }
+            else { float4 u4; u4.x = vb[0]; u4.y = vb[1]; u4.z = vb[2]; u4.w = vb[3]; *reinterpret_cast<float4*>(&Bs[br[i] * FC_PITCH + 4 * bq[i]]) = u4; }
         }
     };
 
@@ -296,8 +315,17 @@ fc_gemm_k(FcJobs js) {
     while (j + 1 < js.n && (int)blockIdx.x >= js.first[j + 1]) ++j;
     const FcArgs& p = js.job[j];
     const int b = (int)blockIdx.x - js.first[j];
-    if (p.a_vec) { if (p.b_vec) fc_body<W, true, true>(p, b, As, Bs); else fc_body<W, true, false>(p, b, As, Bs); }
-    else { if (p.b_vec) fc_body<W, false, true>(p, b, As, Bs); else fc_body<W, false, false>(p, b, As, Bs); }
+    switch (p.a_vec * 3 + p.b_vec) {
+        case 0: fc_body<W, 0, 0>(p, b, As, Bs); break;
+        case 1: fc_body<W, 0, 1>(p, b, As, Bs); break;
+        case 2: fc_body<W, 0, 2>(p, b, As, Bs); break;
+        case 3: fc_body<W, 1, 0>(p, b, As, Bs); break;
+        case 4: fc_body<W, 1, 1>(p, b, As, Bs); break;
+        case 5: fc_body<W, 1, 2>(p, b, As, Bs); break;
+        case 6: fc_body<W, 2, 0>(p, b, As, Bs); break;
+        case 7: fc_body<W, 2, 1>(p, b, As, Bs); break;
+        default: fc_body<W, 2, 2>(p, b, As, Bs); break;
+    }
 }
 
 // split-K: C = epilogue(sum_z ws[z]) in a fixed order, for every job that was split
@@ -333,8 +361,9 @@ int fc_prepare(const vg_fc_job* jb, FcArgs* p) {
     p->d = *d; p->A = jb->A; p->amask = (d->flags & VG_FC_A_MASK) ? jb->amask : nullptr; p->B = jb->B; p->bias = jb->bias; p->cmask = jb->cmask;
     p->C = jb->C; p->cx = jb->cx; p->ws = jb->ws; p->kchunk = kchunk;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    p->a_vec = d->a_sk == 1 && d->K % 4 == 0 && d->a_sm % 4 == 0 && d->a_sb % 4 == 0 && al16(jb->A) && (!p->amask || al16(p->amask));
-    p->b_vec = d->b_sk == 1 && d->K % 4 == 0 && d->b_sn % 4 == 0 && d->b_sb % 4 == 0 && al16(jb->B);
+    const bool a_al = al16(jb->A) && (!p->amask || al16(p->amask)) && d->a_sb % 4 == 0, b_al = al16(jb->B) && d->b_sb % 4 == 0;
+    p->a_vec = (d->a_sk == 1 && d->K % 4 == 0 && d->a_sm % 4 == 0 && a_al) ? 1 : (d->a_sm == 1 && d->a_sk != 1 && d->M % 4 == 0 && d->a_sk % 4 == 0 && a_al) ? 2 : 0;
+    p->b_vec = (d->b_sk == 1 && d->K % 4 == 0 && d->b_sn % 4 == 0 && b_al) ? 1 : (d->b_sn == 1 && d->b_sk != 1 && d->N % 4 == 0 && d->b_sk % 4 == 0 && b_al) ? 2 : 0;
     const int NW = d->N + ((d->flags & VG_FC_B_ONES) ? 1 : 0);
     // 32 x 32 tiles (several blocks per CU hide the round trips) until they number >= 768 per launch-job; then 64 x 64 (4x the MFMAs per
     // LDS byte and barrier: fc8 forward / weight gradient / split data gradient)
