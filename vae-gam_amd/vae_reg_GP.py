@@ -172,10 +172,6 @@ class VAE(nn.Module):
             self._gain_param(c.name, 'logstd', 'logstd_', torch.normal(0, 1, size=(1, 1)))
         self._build_network()
         self.to(self.device)
-        if self.device.type == 'cuda' and os.environ.get('VG_BLAS', 'cublas') != 'default':
-            # the fully connected layers are tiny GEMMs (M = 32..128): rocBLAS ("cublas" in torch's naming) picks faster kernels
-            # for them than hipBLASLt on MI355X (3.87 vs 3.95 ms/step); VG_BLAS=cublaslt / default to change or leave torch's choice
-            torch.backends.cuda.preferred_blas_library(os.environ.get('VG_BLAS', 'cublas'))
         named = list(self.named_parameters())
         head_groups = [['fc31.weight', 'fc32.weight', 'fc33.weight'], ['fc31.bias', 'fc32.bias', 'fc33.bias'],
                        ['fc41.weight', 'fc42.weight', 'fc43.weight'], ['fc41.bias', 'fc42.bias', 'fc43.bias']]
