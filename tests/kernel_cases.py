@@ -39,6 +39,9 @@ WIDE_LAYERS = [
     # 33 positions per row (the first and the last layer of the 41x49x35 network): the weight-gradient rows as three compile-time blocks
     ('conv1_w33', ConvSpec('conv', 1, 8, (3, 3, 3), 1), (4, 5, 35)),
     ('convt5_w33', ConvSpec('convt', 8, 1, (3, 3, 3), 1), (3, 4, 33)),
+    # 30 / 32 positions per row (the large layers of the 82x98x70 network): two compile-time blocks of 4 k-steps
+    ('convt3_w30', ConvSpec('convt', 16, 8, (3, 3, 3), 1), (3, 4, 30)),
+    ('convt4hr_w32', ConvSpec('convt', 8, 8, (4, 4, 4), 2), (3, 3, 32)),
 ]
 
 
