@@ -229,6 +229,27 @@ __device__ __forceinline__ void vg_mfma16(float a, float b, vg_f32x4& acc) {
 struct __attribute__((packed, aligned(4))) vg_f2u { float a, b; };
 __device__ __forceinline__ void vg_store2(float* p, float a, float b) { vg_f2u v; v.a = a; v.b = b; *reinterpret_cast<vg_f2u*>(p) = v; }
 
+// Sum over the 64 lanes of a wave, returned in every lane.  On the GPU: six DPP adds inside the vector ALU (row shifts 1, 2, 4, 8, then
+// the two row broadcasts; the total lands in lane 63 and is read back as a scalar) instead of six ds_bpermute round trips through the
+// LDS pipe per __shfl_down reduction -- the fused GAM/ELBO backward does 8 of them per sample and wave.
+#ifdef VG_EMU
+static inline float vg_wave_sum(float v) {
+    EmuWave& w = g_emu_block->waves[emu_tid / 64]; const int lane = emu_tid % 64;
+    w.fbuf[lane] = v; emu_wait(w.bar);
+    float r = 0.f; for (int l = 0; l < w.lanes; ++l) r += w.fbuf[l];
+    emu_wait(w.bar); return r;
+}
+#else
+__device__ __forceinline__ float vg_wave_sum(float v) {
+#define VG_DPP_ADD(ctrl, rmask) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+    VG_DPP_ADD(0x111, 0xf); VG_DPP_ADD(0x112, 0xf); VG_DPP_ADD(0x114, 0xf); VG_DPP_ADD(0x118, 0xf);      // row_shr:1 2 4 8: inclusive scan in each row of 16
+    VG_DPP_ADD(0x142, 0xa);                                                                               // row_bcast:15 into rows 1, 3
+    VG_DPP_ADD(0x143, 0xc);                                                                               // row_bcast:31 into rows 2, 3
+#undef VG_DPP_ADD
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+#endif
+
 // a value the optimiser may not see through, pinned to a vector register (it would turn 0/1 factors and all-ones/zero masks back into
 // boolean predicates, i.e. scalar register pairs)
 #ifdef VG_EMU

@@ -18,11 +18,7 @@ constexpr int GV = 4;            // voxels per thread (strided by GT -> coalesce
 constexpr int GMAXC = 16;        // covariates supported by the LDS reduction scratch
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 
-__device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    return v;
-}
+__device__ __forceinline__ float wsum(float v) { return vg_wave_sum(v); }     // (every lane gets the sum; callers use lane 0's)
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
 
 // grid (vchunks, B).  part_slp[b][chunk], part_d2[i][b][chunk]
